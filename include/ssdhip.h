@@ -1,0 +1,155 @@
+/*
+ * ssdhip.h -- C ABI of libssdhip.so, the MI355X (gfx950) implementation of the SSD300 hot path of
+ * rs1004/object-detection-torch2.
+ *
+ * The reference has no FFI layer: its boundary is the Python surface `model.SSD` + `utils.*`
+ * (SURVEY.md 8(b)).  Each entry point below replaces the stock-ATen work behind one reference
+ * call site (cited per function, paths relative to the reference's src/).  The Python host layer
+ * (object_detection_torch2_amd/) mirrors the reference surface and binds these with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer borrowed for the call (caller-owned, e.g. torch storage);
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous and stream-ordered;
+ *   - no hidden allocation, no host sync, no global mutable state: workspaces are caller-supplied,
+ *     so every call can be captured into a hipGraph;
+ *   - return 0 on success, a negative SSDHIP_E* code on bad arguments / launch failure
+ *     (the Python side turns it into ValueError / RuntimeError, the reference's error style);
+ *   - activations are NHWC fp32 with C a power of two >= 4 (the 3-channel image is padded to 4);
+ *     NCHW exists only at the API edge (input image, OIHW state_dict weights).
+ */
+#ifndef SSDHIP_H
+#define SSDHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSDHIP_OK 0
+#define SSDHIP_EINVAL (-1)   /* bad shape / argument            */
+#define SSDHIP_ELAUNCH (-2)  /* hipLaunch / runtime error       */
+#define SSDHIP_ENOSUP (-3)   /* configuration not supported     */
+
+/* library / device probe (no reference equivalent) */
+int ssdhip_version(void);
+const char* ssdhip_last_error(void);
+
+/* ---- A9  SSD._get_default_bboxes (model/ssd.py:108-133) ------------------------------------------------
+ * out: (P,4) fp32 rows [cx,cy,w,h]; grid table maps[k] = {m, n, anchors}; computed in fp64, rounded once.  */
+int ssdhip_default_boxes(float* out, const int32_t* maps_host, int n_maps, float s_min, float s_max, void* stream);
+
+/* ---- A2  VGG16.normalize (model/vgg16.py:103-115) fused with NCHW -> NHWC4 -----------------------------
+ * x: (N,3,H,W) -> y: (N,H,W,4), y[...,c] = (x-mean[c])/std[c], y[...,3] = 0.                               */
+int ssdhip_normalize_nchw_to_nhwc4(const float* x, float* y, int N, int H, int W, void* stream);
+
+/* ---- weights: OIHW state_dict tensor -> packed implicit-GEMM operand ------------------------------------
+ * mode 0 (fwd):   packed[co][ (r*S+s)*CinP + ci ]      rows co < CoutP (zero-filled beyond Cout/Cin/taps), row length KP
+ * mode 1 (dgrad): packed[ci][ (r*S+s)*CoutP + co ]     rows ci < CinRowsP, row length KP
+ * (model/ssd.py:61,70-77 nn.Conv2d weights; repacked after each optimizer step for trainable layers)     */
+int ssdhip_pack_conv_weight(const float* w_oihw, float* packed, int Cout, int Cin, int R, int S,
+                            int rows_pad, int inner_pad, int KP, int mode, void* stream);
+
+/* ---- A3/A7  nn.Conv2d forward as NHWC implicit GEMM on v_mfma_f32_32x32x2_f32 ---------------------------
+ * (model/vgg16.py:33, model/ssd.py:61,70-77,103-104).  Also used for dgrad (mode 1) with mode-1 packed weights.
+ * Optional fused input transform: a = relu(x*in_scale[c] + in_shift[c]) applied while staging (train-mode
+ * BatchNorm2d + ReLU of the producer layer, model/vgg16.py:34-35), zero padding applied after it.
+ * Optional epilogue: + bias[co]; per-(m-block, channel) partial sum / sum-of-squares for BatchNorm statistics. */
+typedef struct {
+    const float* x;         /* input activations (N,Hi,Wi,Cin)                                   */
+    const float* w;         /* packed weights (see ssdhip_pack_conv_weight)                      */
+    const float* bias;      /* (Cout) or NULL                                                    */
+    const float* in_scale;  /* (Cin) or NULL: fused BN+ReLU of the input                         */
+    const float* in_shift;  /* (Cin)                                                             */
+    float* y;               /* output base; element (n,ho,wo,co) at y[n*y_batch_stride + (ho*Wo+wo)*Cout + co] */
+    float* stats;           /* NULL or (ceil(M/BM), Cout, 2) partial [sum, sumsq] per m-block     */
+    int64_t y_batch_stride; /* floats between images in y (Ho*Wo*Cout for dense NHWC)            */
+    int32_t N, Hi, Wi, Cin; /* Cin: power of two >= 4                                            */
+    int32_t Ho, Wo, Cout;
+    int32_t R, S, stride, pad;
+    int32_t KP;             /* packed row length (multiple of 32)                                */
+    int32_t mode;           /* 0 fwd gather, 1 dgrad gather (x = dy, roles of Hi/Ho swapped by caller) */
+    int32_t accumulate;     /* 1: y += result (second dgrad contribution)                        */
+    int32_t tile;           /* 0 auto, else BM*1000+BN (128128, 128064, 064128, 064064)          */
+} ssdhip_conv_params;
+int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream);
+/* m-block size the auto/explicit tile choice will use for `stats` (rows of the partial table = ceil(M/BM)) */
+int ssdhip_conv2d_block_m(const ssdhip_conv_params* p);
+
+/* ---- A4  nn.BatchNorm2d, training=True (model/vgg16.py:34, model/ssd.py:62) -----------------------------
+ * partial (MB,C,2) -> scale = gamma*rsqrt(var+eps), shift = beta-mean*scale (biased var); running stats EMA with
+ * momentum and unbiased var, exactly nn.BatchNorm2d; save_mean/save_invstd (C) for backward (may be NULL).
+ * ws: >= 64*C*2 doubles scratch.  count = N*H*W must be > 1 (reference raises ValueError otherwise).       */
+int ssdhip_bn_finalize(const float* partial, int MB, int C, int64_t count, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float momentum, float eps,
+                       float* scale, float* shift, float* save_mean, float* save_invstd, double* ws, void* stream);
+/* eval-mode BatchNorm2d folded to scale/shift from running stats */
+int ssdhip_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                        float eps, int C, float* scale, float* shift, void* stream);
+
+/* ---- A4-A6  BN-apply + ReLU (+ MaxPool2d(2,2,pad)) (model/vgg16.py:28-35) ------------------------------
+ * y = maxpool(relu(x*scale+shift)); pad rows/cols contribute -inf like F.max_pool2d.  pool=0: no pooling.   */
+int ssdhip_bn_relu_pool(const float* x, const float* scale, const float* shift, float* y,
+                        int N, int H, int W, int C, int pool, int pool_pad, void* stream);
+
+/* ---- A10-A16  SSD.loss (model/ssd.py:181-328) -----------------------------------------------------------
+ * outputs (N,P,4+C), targets (N,G,4+C) zero-padded rows, default boxes (P,4).
+ * terms (3,N,P): l_loc, l_conf_pos, l_conf_neg;  cnt (N) int32 scratch;  sel (N,8) fp32:
+ *   [thr_pos, thr_neg, pos_k, neg_k, inv_pos, per_image_loss, 0, 0];  loss (1).
+ * Matching is bit-exact w.r.t. the reference's fp32 op order (no FMA contraction, IEEE divide).             */
+int ssdhip_multibox_loss_fwd(const float* outputs, const float* targets, const float* dboxes,
+                             int N, int P, int G, int C, float alpha, float threshold,
+                             float* terms, int32_t* cnt, float* sel, float* loss, void* stream);
+/* grad (N,P,4+C) = d loss / d outputs * grad_out[0]  (autograd of ssd.py:226-227; masks are constants)    */
+int ssdhip_multibox_loss_bwd(const float* outputs, const float* targets, const float* dboxes,
+                             int N, int P, int G, int C, float alpha, float threshold,
+                             const float* terms, const float* sel, const float* grad_out, float* grad, void* stream);
+/* (N,P,G) uint8 match mask of SSD._match (model/ssd.py:231-250), for parity tests and evaluation            */
+int ssdhip_match_mask(const float* targets, const float* dboxes, int N, int P, int G, int row,
+                      float threshold, uint8_t* mask, void* stream);
+
+/* ---- A19+A20  utils.calc_coordicate + utils.calc_score (utils.py:19-55), in place on (N,P,4+C) ----------- */
+int ssdhip_decode_score(float* outputs, const float* dboxes, int N, int P, int C, void* stream);
+/* ---- A21  utils.calc_iou (utils.py:58-77): t (N,T,rowt), s (N,S,rows) -> (N,T,S) ------------------------- */
+int ssdhip_calc_iou(const float* t, const float* s, int N, int T, int S, int rowt, int rows, float* iou, void* stream);
+/* ---- A22  utils.non_maximum_suppression (utils.py:80-116): greedy, class-agnostic, strict '>' -------------
+ * outputs (N,P,4+C) decoded+scored; zeroes outputs[n,p,4:] of suppressed / void rows in place.
+ * keep (N,P) uint8 (optional, may be NULL).  P <= 16384.                                                    */
+int ssdhip_nms(float* outputs, int N, int P, int C, float iou_thresh, uint8_t* keep, void* stream);
+
+/* ---- backward of the trainable tail (autograd of model/ssd.py:49-77 layers; train.py:121) ---------------- */
+/* wgrad: dW (Cout,R,S,Cin)->written in OIHW state_dict layout, db (Cout) optional.
+ * x (N,Hi,Wi,Cin) with the same optional fused BN+ReLU input transform as the forward; dy (N,Ho,Wo,Cout) element
+ * (n,ho,wo,co) at dy[n*dy_batch_stride + (ho*Wo+wo)*Cout + co].  ws: split-K scratch, ssdhip_conv2d_wgrad_ws_bytes. */
+typedef struct {
+    const float* x; const float* dy; const float* in_scale; const float* in_shift;
+    float* dw_oihw; float* dbias; float* ws;
+    int64_t dy_batch_stride;
+    int32_t N, Hi, Wi, Cin, Ho, Wo, Cout, R, S, stride, pad;
+} ssdhip_wgrad_params;
+int64_t ssdhip_conv2d_wgrad_ws_bytes(const ssdhip_wgrad_params* p);
+int ssdhip_conv2d_wgrad(const ssdhip_wgrad_params* p, void* stream);
+
+/* BatchNorm2d(train)+ReLU backward.  z raw conv output (M,C); da grad w.r.t. relu output.
+ * pass 1: partial sums of dy=da*(z*scale+shift>0) and dy*xhat -> (MB,C,2);  pass 2 (after finalize):
+ * dz = scale*(dy - mean(dy) - xhat*mean(dy*xhat)), dgamma, dbeta.                                           */
+int ssdhip_bn_relu_bwd_reduce(const float* z, const float* da, const float* scale, const float* shift,
+                              const float* save_mean, const float* save_invstd, int64_t M, int C,
+                              float* partial, int MB_rows, void* stream);
+int ssdhip_bn_relu_bwd_finalize(const float* partial, int MB, int C, int64_t M, float* dgamma, float* dbeta,
+                                float* coef /* (C,2): mean_dy, mean_dy_xhat */, double* ws, void* stream);
+int ssdhip_bn_relu_bwd_apply(const float* z, const float* da, const float* scale, const float* shift,
+                             const float* save_mean, const float* save_invstd, const float* coef,
+                             int64_t M, int C, float* dz, void* stream);
+
+/* ---- A17  torch.optim.Adam(lr, weight_decay) step over many tensors (train.py:97,122) -------------------
+ * table (n_tensors,4) device pointers {param, grad, exp_avg, exp_avg_sq}, sizes (n_tensors) int64 element counts,
+ * blockmap: (n_blocks,2) int32 {tensor, chunk} built by the host.  L2 decay added to grad (not AdamW).       */
+int ssdhip_adam_multi_tensor(const void* const* table, const int64_t* sizes, const int32_t* blockmap, int n_blocks,
+                             int chunk, float lr, float beta1, float beta2, float eps, float weight_decay,
+                             float bias_c1, float bias_c2, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSDHIP_H */

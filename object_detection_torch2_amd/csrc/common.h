@@ -1,0 +1,45 @@
+// Shared helpers for libssdhip (gfx950 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/ssdhip.h"
+
+#define WAVE 64
+
+extern "C" void ssdhip_set_error(const char* msg);
+
+#define SSDHIP_REQUIRE(cond, msg)                 \
+    do {                                          \
+        if (!(cond)) {                            \
+            ssdhip_set_error(msg);                \
+            return SSDHIP_EINVAL;                 \
+        }                                         \
+    } while (0)
+
+#define SSDHIP_CHECK_LAUNCH()                                  \
+    do {                                                       \
+        hipError_t e__ = hipGetLastError();                    \
+        if (e__ != hipSuccess) {                               \
+            ssdhip_set_error(hipGetErrorString(e__));          \
+            return SSDHIP_ELAUNCH;                             \
+        }                                                      \
+    } while (0)
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}

@@ -1,0 +1,369 @@
+"""CPU oracle for the SSD300 hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product path (object_detection_torch2_amd) never does and
+fails loudly when its HIP library is missing.
+
+It is a restatement of the reference algorithm written from SURVEY.md, not a
+copy: box / matching / mining / loss / NMS arithmetic is numpy fp32 in the
+reference's operation order (bit-exact targets), and the dense floating-point
+layers (conv / batch-norm / max-pool) call stock torch CPU ops, because that is
+the third-party arithmetic the reference itself delegates to (PyTorch, version
+unpinned by the reference: docker/Dockerfile:2).
+
+Pinning: the reference has no tests or golden vectors, so this
+oracle is pinned by tests/golden/*.npz, generated HERE by importing the
+reference's own model/utils modules on CPU (tests/golden/make_golden.py).
+"""
+import math
+import numpy as np
+
+f32 = np.float32
+
+# ----------------------------------------------------------------------------
+# topology (src/model/vgg16.py:25-37, src/model/ssd.py:28-77)
+# ----------------------------------------------------------------------------
+VGG_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M_P', 512, 512, 512, 'M', 512, 512, 512, 'M_P']
+EXTRA_CFG = [[(3, 1024, 1, 1)], [(1, 1024, 1, 0)], [(1, 256, 1, 0), (3, 512, 2, 1)],
+             [(1, 128, 1, 0), (3, 256, 2, 1)], [(1, 128, 1, 0), (3, 256, 1, 0)], [(1, 128, 1, 0), (3, 256, 1, 0)]]
+DET_CFG = [('4_3', 512, 4), ('7_1', 1024, 6), ('8_2', 512, 6), ('9_2', 256, 6), ('10_2', 256, 4), ('11_2', 256, 4)]
+BOX_CFG = [[38, 38, 4], [19, 19, 6], [10, 10, 6], [5, 5, 6], [3, 3, 4], [1, 1, 4]]
+MEAN = (0.485, 0.456, 0.406)
+STD = (0.229, 0.224, 0.225)
+
+
+def feature_layers():
+    """Ordered feature layer table: dicts with kind conv/bn/act/pool (ssd.py:28-66)."""
+    layers, cin, stage, sub = [], 3, 1, 1
+    for v in VGG_CFG:
+        if v in ('M', 'M_P'):
+            if stage < 5:                                   # pool_5 dropped, ssd.py:38
+                layers.append(dict(kind='pool', name=f'pool_{stage}', pad=1 if v == 'M_P' else 0))
+            stage, sub = stage + 1, 1
+        else:
+            tag = f'{stage}_{sub}'
+            layers.append(dict(kind='conv', name=f'conv_{tag}', cin=cin, cout=v, k=3, stride=1, pad=1, frozen=True))
+            layers.append(dict(kind='bn', name=f'bn_{tag}', c=v, frozen=True))
+            layers.append(dict(kind='act', name=f'act_{tag}'))
+            cin, sub = v, sub + 1
+    for group in EXTRA_CFG:
+        sub = 1
+        for (k, v, s, p) in group:
+            tag = f'{stage}_{sub}'
+            layers.append(dict(kind='conv', name=f'conv_{tag}', cin=cin, cout=v, k=k, stride=s, pad=p, frozen=False))
+            layers.append(dict(kind='bn', name=f'bn_{tag}', c=v, frozen=False))
+            layers.append(dict(kind='act', name=f'act_{tag}'))
+            cin, sub = v, sub + 1
+        stage += 1
+    return layers
+
+
+def detector_layers(num_classes=21):
+    return [dict(name=f'det_{t}', src=f'act_{t}', cin=c, cout=a * (num_classes + 4), anchors=a) for t, c, a in DET_CFG]
+
+
+def trainable_param_names(num_classes=21):
+    """Order of SSD.train_params() (ssd.py:160-179)."""
+    out = []
+    for l in feature_layers():
+        if l['kind'] in ('conv', 'bn') and not l['frozen']:
+            out += [f"features.{l['name']}.weight", f"features.{l['name']}.bias"]
+    for d in detector_layers(num_classes):
+        out += [f"detectors.{d['name']}.weight", f"detectors.{d['name']}.bias"]
+    return out
+
+
+# ----------------------------------------------------------------------------
+# A9 default boxes (ssd.py:108-133): python doubles rounded once to fp32
+# ----------------------------------------------------------------------------
+def default_bboxes():
+    def s_(k, m=6, s_min=0.2, s_max=0.9):
+        return s_min + (s_max - s_min) * (k - 1) / (m - 1)
+    rows = []
+    for k, (m, n, a_num) in enumerate(BOX_CFG, start=1):
+        aspects = [1, 2, 1 / 2, 'add'] if a_num == 4 else [1, 2, 1 / 2, 3, 1 / 3, 'add']
+        for i in range(m):
+            for j in range(n):
+                for a in aspects:
+                    if a == 'add':
+                        w = h = (s_(k) * s_(k + 1)) ** 0.5
+                    else:
+                        w = s_(k) * (a ** 0.5)
+                        h = s_(k) * ((1 / a) ** 0.5)
+                    rows.append(((i + 0.5) / m, (j + 0.5) / n, w, h))   # cx follows the ROW index (Q4)
+    return np.asarray(rows, dtype=np.float64).astype(f32)
+
+
+# ----------------------------------------------------------------------------
+# A10-A16 MultiBox loss (ssd.py:181-328), numpy fp32, reference op order
+# ----------------------------------------------------------------------------
+def match(gt, df, threshold=0.25):
+    """(N,G,>=4),(P,4) -> (N,P,G) bool.  ssd.py:231-250; every op is a separately rounded fp32 op."""
+    g = gt[:, None, :, :4].astype(f32)
+    d = df[None, :, None, :].astype(f32)
+    g_cx, g_cy, g_w, g_h = (g[..., i] for i in range(4))
+    d_cx, d_cy, d_w, d_h = (d[..., i] for i in range(4))
+    two = f32(2)
+    w = np.maximum(np.minimum(g_cx + g_w / two, d_cx + d_w / two) - np.maximum(g_cx - g_w / two, d_cx - d_w / two), f32(0))
+    h = np.maximum(np.minimum(g_cy + g_h / two, d_cy + d_h / two) - np.maximum(g_cy - g_h / two, d_cy - d_h / two), f32(0))
+    ga = g_w * g_h
+    with np.errstate(divide='ignore', invalid='ignore'):
+        iou = np.where(ga > 0, (w * h) / (ga + d_w * d_h - w * h), ga)
+    return iou > f32(threshold)
+
+
+def calc_delta(gt, df):
+    """g-hat (N,P,G,4), ssd.py:252-272 (no variance scaling)."""
+    g = gt[:, None, :, :4].astype(f32)
+    d = df[None, :, None, :].astype(f32)
+    out = np.empty(np.broadcast_shapes(g.shape, d.shape), dtype=f32)
+    out[..., 0] = (g[..., 0] - d[..., 0]) / d[..., 2]
+    out[..., 1] = (g[..., 1] - d[..., 1]) / d[..., 3]
+    with np.errstate(divide='ignore', invalid='ignore'):
+        out[..., 2] = np.where(g[..., 2] > 0, np.log(np.where(g[..., 2] > 0, g[..., 2], f32(1)) / d[..., 2]), g[..., 2])
+        out[..., 3] = np.where(g[..., 3] > 0, np.log(np.where(g[..., 3] > 0, g[..., 3], f32(1)) / d[..., 3]), g[..., 3])
+    return out
+
+
+def smooth_l1(x):
+    ax = np.abs(x)
+    return np.where(ax < 1, f32(0.5) * x * x, ax - f32(0.5)).astype(f32)
+
+
+def log_softmax(x):
+    """F.log_softmax(dim=-1) (ssd.py:298): x - max - log(sum(exp(x - max)))."""
+    m = x.max(axis=-1, keepdims=True)
+    z = (x - m).astype(f32)
+    return (z - np.log(np.exp(z).sum(axis=-1, keepdims=True, dtype=f32))).astype(f32)
+
+
+def split_pos_neg(pos_num, neg_num):
+    """ssd.py:300-311, integer exact."""
+    cond = pos_num * 3 > neg_num
+    return np.where(cond, neg_num // 3, pos_num), np.where(cond, neg_num, pos_num * 3)
+
+
+def k_plus_1_th_value(v, k):
+    """ssd.py:313-328: k>0 -> (k+1)-th largest (= kthvalue(P-k) ascending); k==0 -> max."""
+    if k > 0:
+        return np.partition(v, len(v) - k - 1)[len(v) - k - 1]
+    return v.max()
+
+
+def loss_terms(outputs, targets, df, a=1.0):
+    """Per-(n,p) terms of SSD.loss.  Returns dict with is_match (N,P,G), l_loc, l_conf_pos, l_conf_neg (N,P),
+    pos_num/neg_num after split (N,), kth thresholds, pos_valid/neg_valid (N,P), loss scalar (fp32)."""
+    outputs = outputs.astype(f32); targets = targets.astype(f32); df = df.astype(f32)
+    N, P, _ = outputs.shape
+    G = targets.shape[1]
+    is_match = match(targets, df)                                    # ssd.py:199
+    ghat = calc_delta(targets, df)                                   # ssd.py:203
+    lsm = log_softmax(outputs[:, :, 4:])                             # (N,P,C)
+    l_loc = np.zeros((N, P), f32); l_conf_pos = np.zeros((N, P), f32)
+    for g in range(G):                                               # sum(dim=2) runs g = 0..G-1 in order
+        d = outputs[:, :, :4] - ghat[:, :, g, :]
+        sl = smooth_l1(d)
+        s4 = ((sl[..., 0] + sl[..., 1]) + sl[..., 2]) + sl[..., 3]
+        m = is_match[:, :, g].astype(f32)
+        l_loc = l_loc + s4 * m                                       # ssd.py:204
+        ce = -(targets[:, None, g, 4:] * lsm).sum(axis=-1, dtype=f32)   # ssd.py:298, one-hot -> -lsm[label]
+        l_conf_pos = l_conf_pos + ce * m                             # ssd.py:209
+    not_match = is_match.sum(axis=2) == 0
+    l_conf_neg = (-lsm[:, :, 0]) * not_match.astype(f32)             # ssd.py:212-215
+    pos_num = (is_match.sum(axis=2) != 0).sum(axis=1).astype(np.int64)
+    neg_num = P - pos_num
+    pos_k, neg_k = split_pos_neg(pos_num, neg_num)                   # ssd.py:218-220
+    thr_pos = np.array([k_plus_1_th_value(l_conf_pos[i], int(pos_k[i])) for i in range(N)], f32)
+    thr_neg = np.array([k_plus_1_th_value(l_conf_neg[i], int(neg_k[i])) for i in range(N)], f32)
+    pos_valid = l_conf_pos > thr_pos[:, None]                        # strict, ssd.py:222
+    neg_valid = l_conf_neg > thr_neg[:, None]
+    inv = np.where(pos_k > 0, f32(1) / np.maximum(pos_k, 1).astype(f32), f32(0)).astype(f32)
+    per_prior = (f32(a) * l_loc + l_conf_pos) * pos_valid + l_conf_neg * neg_valid
+    per_image = per_prior.sum(axis=1, dtype=np.float64).astype(f32) * inv
+    loss = f32(per_image.sum(dtype=np.float64) / N)
+    return dict(is_match=is_match, l_loc=l_loc, l_conf_pos=l_conf_pos, l_conf_neg=l_conf_neg, pos_num=pos_k,
+                neg_num=neg_k, thr_pos=thr_pos, thr_neg=thr_neg, pos_valid=pos_valid, neg_valid=neg_valid,
+                inv_pos=inv, per_image=per_image, loss=loss, ghat=ghat, lsm=lsm)
+
+
+def loss(outputs, targets, df, a=1.0):
+    return loss_terms(outputs, targets, df, a)['loss']
+
+
+def loss_grad(outputs, targets, df, a=1.0, grad_out=1.0):
+    """Analytic dL/d outputs (N,P,4+C) of SSD.loss: the masks (is_match, pos_valid, neg_valid) and the
+    normaliser are constants under autograd (comparisons / integer ops), ssd.py:218-227."""
+    t = loss_terms(outputs, targets, df, a)
+    outputs = outputs.astype(f32); targets = targets.astype(f32)
+    N, P, _ = outputs.shape
+    G = targets.shape[1]
+    grad = np.zeros_like(outputs, dtype=f32)
+    sm = np.exp(t['lsm'])
+    coef = (t['inv_pos'] * f32(grad_out) / f32(N))[:, None]          # (N,1)
+    wpos = t['pos_valid'].astype(f32) * coef
+    wneg = (t['neg_valid'] & (t['is_match'].sum(axis=2) == 0)).astype(f32) * coef
+    for g in range(G):
+        m = t['is_match'][:, :, g].astype(f32) * wpos                # (N,P)
+        d = outputs[:, :, :4] - t['ghat'][:, :, g, :]
+        with np.errstate(invalid='ignore'):
+            dsl = np.where(np.abs(d) < 1, d, np.sign(d)).astype(f32)
+        grad[:, :, :4] += f32(a) * dsl * m[..., None]
+        onehot = targets[:, None, g, 4:]                             # (N,1,C)
+        grad[:, :, 4:] += (sm * onehot.sum(axis=-1, keepdims=True) - onehot) * m[..., None]
+    void = np.zeros(outputs.shape[2] - 4, f32); void[0] = 1
+    grad[:, :, 4:] += (sm - void) * wneg[..., None]
+    return grad
+
+
+# ----------------------------------------------------------------------------
+# A19-A22 post-process (utils.py:19-116)
+# ----------------------------------------------------------------------------
+def calc_coordicate(pr, df):
+    pr = pr.astype(f32); d = df[None].astype(f32)
+    out = np.empty(pr.shape[:2] + (4,), f32)
+    out[..., 0] = d[..., 2] * pr[..., 0] + d[..., 0]
+    out[..., 1] = d[..., 3] * pr[..., 1] + d[..., 1]
+    out[..., 2] = d[..., 2] * np.exp(pr[..., 2])
+    out[..., 3] = d[..., 3] * np.exp(pr[..., 3])
+    return out
+
+
+def calc_score(pr):
+    """softmax(pr[:,:,4:]) * onehot(argmax): one non-zero per row (utils.py:43-55)."""
+    x = pr[:, :, 4:].astype(f32)
+    m = x.max(axis=-1, keepdims=True)
+    e = np.exp((x - m).astype(f32))
+    sm = (e / e.sum(axis=-1, keepdims=True, dtype=f32)).astype(f32)
+    arg = x.argmax(axis=-1)                                           # first maximal index
+    mask = np.zeros_like(sm); np.put_along_axis(mask, arg[..., None], 1.0, axis=-1)
+    return sm * mask
+
+
+def calc_iou(t, s):
+    """(N,T,>=4),(N,S,>=4) -> (N,T,S), utils.py:58-77 (guard on w*h>0, differs from match())."""
+    t = t[:, :, None, :4].astype(f32); s = s[:, None, :, :4].astype(f32)
+    two = f32(2)
+    w = np.maximum(np.minimum(t[..., 0] + t[..., 2] / two, s[..., 0] + s[..., 2] / two) -
+                   np.maximum(t[..., 0] - t[..., 2] / two, s[..., 0] - s[..., 2] / two), f32(0))
+    h = np.maximum(np.minimum(t[..., 1] + t[..., 3] / two, s[..., 1] + s[..., 3] / two) -
+                   np.maximum(t[..., 1] - t[..., 3] / two, s[..., 1] - s[..., 3] / two), f32(0))
+    inter = w * h
+    with np.errstate(divide='ignore', invalid='ignore'):
+        return np.where(inter > 0, inter / (t[..., 2] * t[..., 3] + s[..., 2] * s[..., 3] - inter), inter)
+
+
+def nms_keep(output, iou_thresh=0.5):
+    """Greedy class-agnostic NMS keep list for one image (P,4+C), utils.py:90-109.
+    Candidates: rows with max(cols 5:) > 0, sorted by that score descending, ties by lower index."""
+    score = output[:, 5:].max(axis=1)
+    order = np.argsort(-score.astype(np.float64), kind='stable')
+    order = order[score[order] > 0]
+    boxes = output[order, :4].astype(f32)
+    alive = np.ones(len(order), bool)
+    for i in range(len(order)):
+        if not alive[i] or i + 1 >= len(order):
+            continue
+        iou = calc_iou(boxes[None, i:i + 1], boxes[None, i + 1:])[0, 0]
+        alive[i + 1:] &= ~(iou > f32(iou_thresh))
+    return order[alive]
+
+
+def non_maximum_suppression(outputs, iou_thresh=0.5):
+    """Mutates outputs[:,:,4:] in place like the reference (utils.py:114) and returns it."""
+    N, P, _ = outputs.shape
+    for n in range(N):
+        mask = np.zeros(P, f32)
+        mask[nms_keep(outputs[n], iou_thresh)] = 1
+        outputs[n, :, 4:] *= mask[:, None]
+    return outputs
+
+
+# ----------------------------------------------------------------------------
+# A2-A8 forward on torch CPU ops (floating-point layers)
+# ----------------------------------------------------------------------------
+def init_state(seed=1, num_classes=21, vgg_random=True):
+    """Reference-keyed state_dict (173 entries) with hash-seeded weights: kaiming fan_out pseudo-normal for every
+    conv (the VGG part too -- no pretrained weights exist offline), bias 0, BN gamma 1 / beta 0 / stats 0,1."""
+    import torch
+    from object_detection_torch2_amd import synth
+    sd, stream = {}, 100
+    def conv(prefix, cout, cin, k):
+        nonlocal stream
+        std = math.sqrt(2.0 / (cout * k * k))
+        w = synth.pseudo_normal(seed, stream, cout * cin * k * k) * std
+        stream += 1
+        sd[prefix + '.weight'] = torch.from_numpy(w.astype(f32).reshape(cout, cin, k, k))
+        sd[prefix + '.bias'] = torch.zeros(cout)
+    for l in feature_layers():
+        if l['kind'] == 'conv':
+            conv('features.' + l['name'], l['cout'], l['cin'], l['k'])
+        elif l['kind'] == 'bn':
+            p = 'features.' + l['name']
+            sd[p + '.weight'] = torch.ones(l['c']); sd[p + '.bias'] = torch.zeros(l['c'])
+            sd[p + '.running_mean'] = torch.zeros(l['c']); sd[p + '.running_var'] = torch.ones(l['c'])
+            sd[p + '.num_batches_tracked'] = torch.tensor(0, dtype=torch.long)
+    for d in detector_layers(num_classes):
+        conv('detectors.' + d['name'], d['cout'], d['cin'], 3)
+    return sd
+
+
+def forward(sd, x, num_classes=21, training=True, collect=None):
+    """Intended SSD.forward contract (N,P,4+C) (ssd.py:86-106 with the Q1 membership fix).
+    sd: state dict of torch tensors (requires_grad honoured); running stats updated in place when training."""
+    import torch
+    import torch.nn.functional as F
+    mean = torch.tensor(MEAN, dtype=torch.float32).reshape(1, 3, 1, 1)
+    std = torch.tensor(STD, dtype=torch.float32).reshape(1, 3, 1, 1)
+    x = x.sub(mean).div(std)                                          # vgg16.py:112-114
+    dets = {d['src']: d for d in detector_layers(num_classes)}
+    ys = []
+    for l in feature_layers():
+        p = 'features.' + l['name']
+        if l['kind'] == 'conv':
+            x = F.conv2d(x, sd[p + '.weight'], sd[p + '.bias'], stride=l['stride'], padding=l['pad'])
+        elif l['kind'] == 'bn':
+            if training:
+                sd[p + '.num_batches_tracked'] += 1
+            x = F.batch_norm(x, sd[p + '.running_mean'], sd[p + '.running_var'], sd[p + '.weight'], sd[p + '.bias'],
+                             training=training, momentum=0.1, eps=1e-5)
+        elif l['kind'] == 'act':
+            x = F.relu(x)
+            if collect is not None:
+                collect[l['name']] = x
+            if l['name'] in dets:
+                d = dets[l['name']]
+                q = 'detectors.' + d['name']
+                y = F.conv2d(x, sd[q + '.weight'], sd[q + '.bias'], padding=1)
+                ys.append(y.permute(0, 2, 3, 1).reshape(x.shape[0], -1, num_classes + 4))
+        else:
+            x = F.max_pool2d(x, 2, 2, padding=l['pad'])
+    return torch.cat(ys, dim=1)
+
+
+def adam_step(p, g, m, v, step, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, wd=5e-4):
+    """torch.optim.Adam single-tensor semantics (train.py:97): L2 decay added to grad, bias-corrected."""
+    g = g + wd * p
+    m[:] = b1 * m + (1 - b1) * g
+    v[:] = b2 * v + (1 - b2) * g * g
+    bc1 = 1 - b1 ** step; bc2 = 1 - b2 ** step
+    p[:] = p - (lr / bc1) * m / (np.sqrt(v) / math.sqrt(bc2) + eps)
+    return p
+
+
+def train_step(sd, opt_state, images, targets_np, df, lr=1e-3, wd=5e-4, num_classes=21):
+    """One reference train-loop body (train.py:115-122) on CPU: forward -> loss -> backward -> Adam.
+    Loss value and dL/d outputs come from the numpy restatement; torch autograd carries it through the layers."""
+    import torch
+    names = trainable_param_names(num_classes)
+    for k in names:
+        sd[k].requires_grad_(True); sd[k].grad = None
+    out = forward(sd, images, num_classes, training=True)
+    o = out.detach().numpy()
+    lval = loss(o, targets_np, df)
+    out.backward(torch.from_numpy(loss_grad(o, targets_np, df)))
+    opt_state['step'] = opt_state.get('step', 0) + 1
+    with torch.no_grad():
+        for k in names:
+            st = opt_state.setdefault(k, dict(m=np.zeros(sd[k].shape, f32), v=np.zeros(sd[k].shape, f32)))
+            adam_step(sd[k].numpy(), sd[k].grad.numpy(), st['m'], st['v'], opt_state['step'], lr=lr, wd=wd)
+    return float(lval)
