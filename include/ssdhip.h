@@ -14,7 +14,7 @@
  *     so every call can be captured into a hipGraph;
  *   - return 0 on success, a negative SSDHIP_E* code on bad arguments / launch failure
  *     (the Python side turns it into ValueError / RuntimeError, the reference's error style);
- *   - activations are NHWC fp32 with C a power of two >= 4 (the 3-channel image is padded to 4);
+ *   - activations are NHWC fp32 with C a multiple of 32 (the 3-channel image is padded to 4);
  *     NCHW exists only at the API edge (input image, OIHW state_dict weights).
  */
 #ifndef SSDHIP_H
@@ -36,8 +36,9 @@ int ssdhip_version(void);
 const char* ssdhip_last_error(void);
 
 /* ---- A9  SSD._get_default_bboxes (model/ssd.py:108-133) ------------------------------------------------
- * out: (P,4) fp32 rows [cx,cy,w,h]; grid table maps[k] = {m, n, anchors}; computed in fp64, rounded once.  */
-int ssdhip_default_boxes(float* out, const int32_t* maps_host, int n_maps, float s_min, float s_max, void* stream);
+ * out: (P,4) fp32 rows [cx,cy,w,h]; HOST table maps[k] = {m, n, anchors}; computed in fp64, rounded once.
+ * Returns P (>0) on success.                                                                              */
+int ssdhip_default_boxes(float* out, const int32_t* maps_host, int n_maps, double s_min, double s_max, void* stream);
 
 /* ---- A2  VGG16.normalize (model/vgg16.py:103-115) fused with NCHW -> NHWC4 -----------------------------
  * x: (N,3,H,W) -> y: (N,H,W,4), y[...,c] = (x-mean[c])/std[c], y[...,3] = 0.                               */
@@ -64,7 +65,7 @@ typedef struct {
     float* y;               /* output base; element (n,ho,wo,co) at y[n*y_batch_stride + (ho*Wo+wo)*Cout + co] */
     float* stats;           /* NULL or (ceil(M/BM), Cout, 2) partial [sum, sumsq] per m-block     */
     int64_t y_batch_stride; /* floats between images in y (Ho*Wo*Cout for dense NHWC)            */
-    int32_t N, Hi, Wi, Cin; /* Cin: power of two >= 4                                            */
+    int32_t N, Hi, Wi, Cin; /* Cin: 4 (padded RGB image) or a multiple of 32                     */
     int32_t Ho, Wo, Cout;
     int32_t R, S, stride, pad;
     int32_t KP;             /* packed row length (multiple of 32)                                */
@@ -124,8 +125,9 @@ int ssdhip_nms(float* outputs, int N, int P, int C, float iou_thresh, uint8_t* k
 typedef struct {
     const float* x; const float* dy; const float* in_scale; const float* in_shift;
     float* dw_oihw; float* dbias; float* ws;
-    int64_t dy_batch_stride;
+    int64_t dy_batch_stride;  /* floats between images in dy (Ho*Wo*dy_row when dense)          */
     int32_t N, Hi, Wi, Cin, Ho, Wo, Cout, R, S, stride, pad;
+    int32_t dy_row;           /* floats per pixel row of dy (>= Cout, multiple of 4; channel padding) */
 } ssdhip_wgrad_params;
 int64_t ssdhip_conv2d_wgrad_ws_bytes(const ssdhip_wgrad_params* p);
 int ssdhip_conv2d_wgrad(const ssdhip_wgrad_params* p, void* stream);
@@ -138,16 +140,23 @@ int ssdhip_bn_relu_bwd_reduce(const float* z, const float* da, const float* scal
                               float* partial, int MB_rows, void* stream);
 int ssdhip_bn_relu_bwd_finalize(const float* partial, int MB, int C, int64_t M, float* dgamma, float* dbeta,
                                 float* coef /* (C,2): mean_dy, mean_dy_xhat */, double* ws, void* stream);
+/* dense loss gradient (N,P,row) -> channel-padded NHWC head gradient (N,HW,Cpad), pad channels zeroed
+ * (feeds dgrad/wgrad of one detector head; inverse of the zero-copy concat of model/ssd.py:103-104)        */
+int ssdhip_scatter_head_grad(const float* grad, float* out, int N, int P, int row, int prior_offset, int HW,
+                             int Cout, int Cpad, void* stream);
 int ssdhip_bn_relu_bwd_apply(const float* z, const float* da, const float* scale, const float* shift,
                              const float* save_mean, const float* save_invstd, const float* coef,
                              int64_t M, int C, float* dz, void* stream);
 
 /* ---- A17  torch.optim.Adam(lr, weight_decay) step over many tensors (train.py:97,122) -------------------
  * table (n_tensors,4) device pointers {param, grad, exp_avg, exp_avg_sq}, sizes (n_tensors) int64 element counts,
- * blockmap: (n_blocks,2) int32 {tensor, chunk} built by the host.  L2 decay added to grad (not AdamW).       */
+ * blockmap: (n_blocks,2) int32 {tensor, chunk} built by the host (all three arrays live in DEVICE memory).
+ * L2 decay added to grad (not AdamW).                                                                        */
 int ssdhip_adam_multi_tensor(const void* const* table, const int64_t* sizes, const int32_t* blockmap, int n_blocks,
-                             int chunk, float lr, float beta1, float beta2, float eps, float weight_decay,
-                             float bias_c1, float bias_c2, float grad_scale, void* stream);
+                             int chunk, const float* hyper, void* stream);
+/* hyper (device, 8 floats): [lr, beta1, beta2, eps, weight_decay, 1-beta1^t, sqrt(1-beta2^t), grad_scale];
+ * adam_tick increments the device step counter and refreshes slots 5,6 (graph-replayable step bookkeeping).  */
+int ssdhip_adam_tick(int32_t* step, float* hyper, void* stream);
 
 #ifdef __cplusplus
 }

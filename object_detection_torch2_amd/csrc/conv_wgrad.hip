@@ -1,0 +1,245 @@
+// Weight gradient of an NHWC convolution on v_mfma_f32_32x32x2_f32 (autograd of nn.Conv2d, model/ssd.py:61,70-77;
+// reached from loss.backward(), train.py:121).
+//
+//   dW[co][tap][ci] = sum_m dy[m][co] * a[pix(m, tap)][ci]        GEMM: rows = co, cols = ci (per tap), K = pixels m
+//   block tile  128 co x 128 ci x 32 pixels for one (tap, k-split); 4 waves (2 x 2), each 64 x 64 = 2 x 2 MFMA tiles
+//   staging     both operands are "k-major" in memory (pixel rows, channel-contiguous), exactly the order the MFMA
+//               wants with k on the lane halves: lane (i, h) reads float2 {row 2kk+h, channels 2i, 2i+1} with one
+//               conflict-free ds_read_b64 and feeds 2 tiles; tile t of a wave owns channels {2i+t}.  No transposes,
+//               no LDS padding.  Input a = relu(bn(z)) is recomputed while staging (same fused transform as forward).
+//   split-K     pixel range split over blocks; partial tiles go to a slab ws[split][co][tap][ci] with plain stores and a
+//               second kernel sums the slabs in fixed order into the OIHW state_dict layout (bit-reproducible, no atomics)
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int TM = 128, TN = 128, TK = 32;
+
+struct WgradArgs {
+    const float* x; const float* dy; const float* in_scale; const float* in_shift; float* ws;
+    long long dy_batch_stride;
+    int M, Hi, Wi, Cin, Ho, Wo, HoWo, Cout, CoutRow, KS, taps, stride, pad;
+    int CB, IB, splitK, stages_per_split, stages, CoutT, CinT;
+};
+
+template <bool XFORM>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TK * TM];
+    float* As = lds;                 // [2][TK][TM]  dy rows
+    float* Bs = lds + 2 * TK * TM;   // [2][TK][TN]  gathered input rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    int b = blockIdx.x;
+    const int ib = b % a.IB; b /= a.IB;
+    const int cb = b % a.CB; b /= a.CB;
+    const int tap = b % a.taps; b /= a.taps;
+    const int split = b;
+    const int co0 = cb * TM, ci0 = ib * TN;
+    const int r = tap / a.KS, s = tap - r * a.KS;
+
+    const int lrow = tid >> 5, col4 = tid & 31;     // 8 rows x 32 float4 per pass, 4 passes
+    const int st0 = split * a.stages_per_split;
+    const int st1 = min(a.stages, st0 + a.stages_per_split);
+
+    float4 sc, sh;
+    const int ci = ci0 + col4 * 4;
+    const bool ci_ok = ci < a.Cin;
+    if (XFORM && ci_ok) {
+        sc = *reinterpret_cast<const float4*>(a.in_scale + ci);
+        sh = *reinterpret_cast<const float4*>(a.in_shift + ci);
+    }
+    const int co = co0 + col4 * 4;
+    const bool co_ok = co < a.CoutRow;
+
+    float4 ra[4], rb[4];
+    auto load_stage = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = st * TK + lrow + 8 * i;
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+            if (m < a.M) {
+                const int n = m / a.HoWo;
+                const int rem = m - n * a.HoWo;
+                if (co_ok) va = *reinterpret_cast<const float4*>(a.dy + (size_t)n * a.dy_batch_stride + (size_t)rem * a.CoutRow + co);
+                const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+                const int hi = ho * a.stride - a.pad + r, wi = wo * a.stride - a.pad + s;
+                if (ci_ok && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi) {
+                    vb = *reinterpret_cast<const float4*>(a.x + ((size_t)(n * a.Hi + hi) * a.Wi + wi) * a.Cin + ci);
+                    if (XFORM) {
+                        vb.x = fmaxf(fmaf(vb.x, sc.x, sh.x), 0.f); vb.y = fmaxf(fmaf(vb.y, sc.y, sh.y), 0.f);
+                        vb.z = fmaxf(fmaf(vb.z, sc.z, sh.z), 0.f); vb.w = fmaxf(fmaf(vb.w, sc.w, sh.w), 0.f);
+                    }
+                }
+            }
+            ra[i] = va; rb[i] = vb;
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4*>(As + (buf * TK + lrow + 8 * i) * TM + col4 * 4) = ra[i];
+            *reinterpret_cast<float4*>(Bs + (buf * TK + lrow + 8 * i) * TN + col4 * 4) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
+
+    if (st0 < st1) {
+        load_stage(st0);
+        store_stage(0);
+    }
+    __syncthreads();
+    const int fi = (lane & 31) * 2, fh = lane >> 5;
+    for (int st = st0; st < st1; ++st) {
+        const int buf = (st - st0) & 1;
+        const bool more = st + 1 < st1;
+        if (more) load_stage(st + 1);
+        const float* Ab = As + (buf * TK + fh) * TM + wm * 64 + fi;
+        const float* Bb = Bs + (buf * TK + fh) * TN + wn * 64 + fi;
+#pragma unroll
+        for (int kk = 0; kk < TK / 2; ++kk) {
+            const float2 fa = *reinterpret_cast<const float2*>(Ab + kk * 2 * TM);
+            const float2 fb = *reinterpret_cast<const float2*>(Bb + kk * 2 * TN);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc[1][1], 0, 0, 0);
+        }
+        if (more) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+    // slab store: ws[split][co][tap][ci]; tile (t,u) element e: co = co0+wm*64+2*row+t, ci = ci0+wn*64+2*(lane&31)+u
+    float* slab = a.ws + (size_t)split * a.CoutT * a.taps * a.CinT;
+    const int cj = ci0 + wn * 64 + (lane & 31) * 2;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            const int cco = co0 + wm * 64 + 2 * row + t;
+            float2 v = make_float2(acc[t][0][e], acc[t][1][e]);
+            *reinterpret_cast<float2*>(slab + ((size_t)cco * a.taps + tap) * a.CinT + cj) = v;
+        }
+}
+
+// dw_oihw[co][ci][tap] = sum_split ws[split][co][tap][ci]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int taps, int CoutT,
+                                    int CinT, int splitK) {
+    const int64_t total = (int64_t)Cout * taps * Cin;
+    const size_t slab = (size_t)CoutT * taps * CinT;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin);
+        int64_t q = i / Cin;
+        const int tap = (int)(q % taps);
+        const int co = (int)(q / taps);
+        const size_t src = ((size_t)co * taps + tap) * CinT + ci;
+        float v = 0.f;
+        for (int s = 0; s < splitK; ++s) v += ws[s * slab + src];
+        dw[((size_t)co * Cin + ci) * taps + tap] = v;
+    }
+}
+
+// column sums of a (M, row) matrix for the first C columns: partial (MB, C, 2) = [sum, 0] (consumed by bn_stats_stage1)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ dy, long long batch_stride, int HoWo,
+                                                             int64_t M, int C, int row, int rows_per_block,
+                                                             float* __restrict__ partial) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int64_t lo = (int64_t)blockIdx.y * rows_per_block, hi = min(M, lo + rows_per_block);
+    float s = 0.f;
+    if (c < C)
+        for (int64_t m = lo + rl; m < hi; m += 4) {
+            const int64_t n = m / HoWo, rem = m - n * HoWo;
+            s += dy[n * batch_stride + rem * row + c];
+        }
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        s += red[1][cl] + red[2][cl] + red[3][cl];
+        partial[((size_t)blockIdx.y * C + c) * 2] = s;
+        partial[((size_t)blockIdx.y * C + c) * 2 + 1] = 0.f;
+    }
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ partial, int MB, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int r = 0; r < MB; ++r) s += (double)partial[((size_t)r * C + c) * 2];
+    out[c] = (float)s;
+}
+
+void plan(const ssdhip_wgrad_params* p, WgradArgs& a) {
+    a.x = p->x; a.dy = p->dy; a.in_scale = p->in_scale; a.in_shift = p->in_shift; a.ws = p->ws;
+    a.dy_batch_stride = p->dy_batch_stride;
+    a.M = p->N * p->Ho * p->Wo; a.Hi = p->Hi; a.Wi = p->Wi; a.Cin = p->Cin; a.Ho = p->Ho; a.Wo = p->Wo; a.HoWo = p->Ho * p->Wo;
+    a.Cout = p->Cout; a.CoutRow = p->dy_row; a.KS = p->S; a.taps = p->R * p->S; a.stride = p->stride; a.pad = p->pad;
+    a.CB = cdiv(p->Cout, TM); a.IB = cdiv(p->Cin, TN);
+    a.CoutT = a.CB * TM; a.CinT = a.IB * TN;
+    a.stages = cdiv(a.M, TK);
+    const int tiles = a.CB * a.IB * a.taps;
+    int sk = cdiv(1024, tiles);
+    if (sk > a.stages / 8) sk = a.stages / 8;
+    if (sk < 1) sk = 1;
+    if (sk > 32) sk = 32;
+    a.stages_per_split = cdiv(a.stages, sk);
+    a.splitK = cdiv(a.stages, a.stages_per_split);
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t ssdhip_conv2d_wgrad_ws_bytes(const ssdhip_wgrad_params* p) {
+    if (!p || p->N <= 0 || p->Cin <= 0 || p->Cout <= 0) return SSDHIP_EINVAL;
+    WgradArgs a;
+    plan(p, a);
+    int64_t slabs = (int64_t)a.splitK * a.CoutT * a.taps * a.CinT * 4;
+    int64_t bias = (int64_t)64 * a.Cout * 2 * 4;
+    return slabs + bias;
+}
+
+int ssdhip_conv2d_wgrad(const ssdhip_wgrad_params* p, void* stream) {
+    SSDHIP_REQUIRE(p && p->x && p->dy && p->dw_oihw && p->ws, "wgrad: null pointer");
+    SSDHIP_REQUIRE(p->Cin % 4 == 0 && p->dy_row % 4 == 0 && p->dy_row >= p->Cout, "wgrad: Cin and dy_row must be multiples of 4");
+    SSDHIP_REQUIRE(p->R == p->S && (p->R == 1 || p->R == 3), "wgrad: 1x1 or 3x3 kernels");
+    SSDHIP_REQUIRE((p->in_scale == nullptr) == (p->in_shift == nullptr), "wgrad: in_scale and in_shift go together");
+    SSDHIP_REQUIRE((int64_t)p->N * p->Hi * p->Wi < (1ll << 31), "wgrad: tensor too large");
+    WgradArgs a;
+    plan(p, a);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(a.CB * a.IB * a.taps * a.splitK), block(256);
+    if (p->in_scale) hipLaunchKernelGGL(wgrad_kernel<true>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(wgrad_kernel<false>, grid, block, 0, st, a);
+    SSDHIP_CHECK_LAUNCH();
+    int64_t total = (int64_t)p->Cout * a.taps * p->Cin;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.ws, p->dw_oihw, p->Cout, p->Cin, a.taps, a.CoutT, a.CinT,
+                       a.splitK);
+    SSDHIP_CHECK_LAUNCH();
+    if (p->dbias) {
+        float* partial = a.ws + (size_t)a.splitK * a.CoutT * a.taps * a.CinT;
+        int MB = cdiv(a.M, 64);
+        if (MB > 64) MB = 64;
+        const int rows_per_block = cdiv(a.M, MB);
+        MB = cdiv(a.M, rows_per_block);
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(p->Cout, 64), MB), dim3(256), 0, st, p->dy, (long long)p->dy_batch_stride,
+                           a.HoWo, (int64_t)a.M, p->Cout, p->dy_row, rows_per_block, partial);
+        SSDHIP_CHECK_LAUNCH();
+        hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(p->Cout, 64)), dim3(64), 0, st, partial, MB, p->Cout, p->dbias);
+        SSDHIP_CHECK_LAUNCH();
+    }
+    return SSDHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,257 @@
+// Inference post-process: box decode + score (utils.py:19-55), pairwise IoU (utils.py:58-77) and the greedy
+// class-agnostic NMS (utils.py:80-116).  Built with -ffp-contract=off so IoU comparisons use the reference's
+// separately-rounded fp32 ops.
+//
+// NMS: one 1024-thread workgroup per image, everything in LDS (160 KiB):
+//   1. candidates (max over class cols 5: > 0) compacted as 64-bit keys  score_bits<<32 | ~index
+//   2. bitonic sort, descending (ties -> lower index first)
+//   3. 64-candidate chunks: all 16 waves test the chunk against the kept list (LDS broadcast reads) and build the
+//      64x64 intra-chunk IoU bit-matrix with __ballot; wave 0 resolves the serial greedy chain on scalar bitmasks
+//   4. rows not kept get their score columns zeroed in place (utils.py:114)
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ bool iou_gt(float4 t, float4 s, float thr) {  // utils.py:74-77, strict '>'
+    float tw2 = t.z / 2.0f, sw2 = s.z / 2.0f, th2 = t.w / 2.0f, sh2 = s.w / 2.0f;
+    float w = fminf(t.x + tw2, s.x + sw2) - fmaxf(t.x - tw2, s.x - sw2);
+    w = fmaxf(w, 0.0f);
+    float h = fminf(t.y + th2, s.y + sh2) - fmaxf(t.y - th2, s.y - sh2);
+    h = fmaxf(h, 0.0f);
+    float wh = w * h;
+    float iou = wh > 0.0f ? wh / (t.z * t.w + s.z * s.w - wh) : wh;
+    return iou > thr;
+}
+
+__device__ __forceinline__ float iou_val(const float* t, const float* s) {
+    float tw2 = t[2] / 2.0f, sw2 = s[2] / 2.0f, th2 = t[3] / 2.0f, sh2 = s[3] / 2.0f;
+    float w = fminf(t[0] + tw2, s[0] + sw2) - fmaxf(t[0] - tw2, s[0] - sw2);
+    w = fmaxf(w, 0.0f);
+    float h = fminf(t[1] + th2, s[1] + sh2) - fmaxf(t[1] - th2, s[1] - sh2);
+    h = fmaxf(h, 0.0f);
+    float wh = w * h;
+    return wh > 0.0f ? wh / (t[2] * t[3] + s[2] * s[3] - wh) : wh;
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void decode_score_kernel(float* __restrict__ outputs, const float* __restrict__ dboxes, int P,
+                                                           int64_t total) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int p = (int)(idx % P);
+    float* row = outputs + idx * (4 + NC);
+    float4 d = reinterpret_cast<const float4*>(dboxes)[p];
+    float v[4 + NC];
+#pragma unroll
+    for (int c = 0; c < 4 + NC; ++c) v[c] = row[c];
+    // utils.calc_coordicate, utils.py:35-38 (mul then add, no fma)
+    float cx = d.z * v[0] + d.x;
+    float cy = d.w * v[1] + d.y;
+    float w = d.z * expf(v[2]);
+    float h = d.w * expf(v[3]);
+    // utils.calc_score, utils.py:54-55: softmax * onehot(argmax) -> one non-zero per row
+    float mx = v[4];
+    int arg = 0;
+#pragma unroll
+    for (int c = 1; c < NC; ++c)
+        if (v[4 + c] > mx) { mx = v[4 + c]; arg = c; }
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) s += expf(v[4 + c] - mx);
+    float score = expf(v[4 + arg] - mx) / s;
+    row[0] = cx; row[1] = cy; row[2] = w; row[3] = h;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) row[4 + c] = (c == arg) ? score : 0.0f;
+}
+
+__global__ void calc_iou_kernel(const float* __restrict__ t, const float* __restrict__ s, int T, int S, int rowt, int rows,
+                                float* __restrict__ iou) {
+    const int n = blockIdx.z;
+    const int si = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ti = blockIdx.y;
+    if (si >= S) return;
+    const float* tp = t + ((size_t)n * T + ti) * rowt;
+    const float* sp = s + ((size_t)n * S + si) * rows;
+    iou[((size_t)n * T + ti) * S + si] = iou_val(tp, sp);
+}
+
+constexpr int NMS_THREADS = 1024;
+constexpr int NMS_WAVES = NMS_THREADS / 64;
+constexpr int NMS_LDS_BYTES = 160 * 1024;
+constexpr int NMS_MISC_BYTES = 64 * 8 + NMS_WAVES * 8 + 64;  // rowmask[64], wmask[16], scalars
+
+__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(float* __restrict__ outputs, int P, int C, float thr,
+                                                          uint8_t* __restrict__ keep_out, int idx_bytes, int kept_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int n = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ROW = 4 + C;
+    float* out = outputs + (size_t)n * P * ROW;
+
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(lds);
+    // regions valid after the sort: idx16 | kept boxes | keepbits | misc
+    unsigned short* idx16 = reinterpret_cast<unsigned short*>(lds);
+    float4* kept = reinterpret_cast<float4*>(lds + idx_bytes);
+    unsigned char* tail = lds + NMS_LDS_BYTES - NMS_MISC_BYTES;
+    unsigned long long* rowmask = reinterpret_cast<unsigned long long*>(tail);
+    unsigned long long* wmask = rowmask + 64;
+    int* scal = reinterpret_cast<int*>(wmask + NMS_WAVES);  // [0] candidate count, [1] kept count
+    unsigned* keepbits = reinterpret_cast<unsigned*>(tail) - ((P + 31) / 32 + 3) / 4 * 4;
+
+    if (tid == 0) { scal[0] = 0; scal[1] = 0; }
+    __syncthreads();
+    // 1. candidate keys, compacted (order irrelevant before the sort; keys are unique)
+    for (int i = tid; i < P; i += NMS_THREADS) {
+        const float* row = out + (size_t)i * ROW;
+        float sc = row[5];
+        for (int c = 6; c < ROW; ++c) sc = fmaxf(sc, row[c]);   // torch.max(output[:, 5:], dim=1), utils.py:99
+        if (sc > 0.0f) {
+            int slot = atomicAdd(&scal[0], 1);
+            keys[slot] = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+        }
+    }
+    __syncthreads();
+    const int K = scal[0];
+    int sortn = 64;
+    while (sortn < K) sortn <<= 1;
+    for (int i = K + tid; i < sortn; i += NMS_THREADS) keys[i] = 0ull;
+    __syncthreads();
+    // 2. bitonic sort, descending
+    for (int k = 2; k <= sortn; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (sortn >> 1); t += NMS_THREADS) {
+                int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                int l = i | j;
+                unsigned long long a = keys[i], b = keys[l];
+                bool desc = (i & k) == 0;
+                if ((a < b) == desc) { keys[i] = b; keys[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    // 3. compact to 16-bit prior indices (registers first: idx16 aliases keys)
+    unsigned short myidx[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int i = tid + r * NMS_THREADS;
+        myidx[r] = (i < K) ? (unsigned short)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull)) : (unsigned short)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int i = tid + r * NMS_THREADS;
+        if (i < K) idx16[i] = myidx[r];
+    }
+    for (int i = tid; i < (P + 31) / 32; i += NMS_THREADS) keepbits[i] = 0u;
+    __syncthreads();
+    // 4. greedy suppression, 64 sorted candidates per chunk
+    const int nchunks = (K + 63) >> 6;
+    for (int c = 0; c < nchunks; ++c) {
+        const int ci = c * 64 + lane;
+        const bool valid = ci < K;
+        const int pidx = valid ? (int)idx16[ci] : 0;
+        float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) {
+            const float* row = out + (size_t)pidx * ROW;
+            box = make_float4(row[0], row[1], row[2], row[3]);
+        }
+        const int nkept = scal[1];
+        // (a) against boxes kept in earlier chunks; waves stride over the kept list
+        bool sup = false;
+        for (int j = wave; j < nkept; j += NMS_WAVES) {
+            float4 kb = kept[j];
+            sup |= iou_gt(kb, box, thr);
+        }
+        unsigned long long sm = __ballot(sup && valid);
+        if (lane == 0) wmask[wave] = sm;
+        // (b1) intra-chunk matrix: wave w owns heads 4w..4w+3; bit j of rowmask[i] = head i suppresses later row j
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = wave * 4 + r;
+            float4 hb;
+            hb.x = __shfl(box.x, i, 64); hb.y = __shfl(box.y, i, 64); hb.z = __shfl(box.z, i, 64); hb.w = __shfl(box.w, i, 64);
+            bool hit = valid && (lane > i) && iou_gt(hb, box, thr);
+            unsigned long long m = __ballot(hit);
+            if (lane == 0) rowmask[i] = m;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            unsigned long long supm = 0ull;
+#pragma unroll
+            for (int w = 0; w < NMS_WAVES; ++w) supm |= wmask[w];
+            unsigned long long alive = __ballot(valid) & ~supm;
+            const unsigned long long mine = rowmask[lane];
+            const unsigned mlo = (unsigned)mine, mhi = (unsigned)(mine >> 32);
+#pragma unroll
+            for (int i = 0; i < 64; ++i) {
+                unsigned lo = __builtin_amdgcn_readlane(mlo, i);
+                unsigned hi = __builtin_amdgcn_readlane(mhi, i);
+                unsigned long long rm = ((unsigned long long)hi << 32) | lo;
+                if ((alive >> i) & 1ull) alive &= ~rm;
+            }
+            const bool is_kept = (alive >> lane) & 1ull;
+            if (is_kept) {
+                int pos = nkept + (int)__popcll(alive & ((1ull << lane) - 1ull));
+                if (pos < kept_cap) kept[pos] = box;
+                atomicOr(&keepbits[pidx >> 5], 1u << (pidx & 31));
+            }
+            if (lane == 0) scal[1] = nkept + (int)__popcll(alive);
+        }
+        __syncthreads();
+    }
+    // 5. outputs[:, :, 4:] *= keep mask (utils.py:114): suppressed, void-argmax and non-candidate rows end all-zero
+    for (int i = tid; i < P; i += NMS_THREADS) {
+        bool k = (keepbits[i >> 5] >> (i & 31)) & 1u;
+        if (keep_out) keep_out[(size_t)n * P + i] = k ? 1 : 0;
+        if (!k) {
+            float* row = out + (size_t)i * ROW;
+            for (int c = 4; c < ROW; ++c) row[c] = row[c] * 0.0f;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssdhip_decode_score(float* outputs, const float* dboxes, int N, int P, int C, void* stream) {
+    SSDHIP_REQUIRE(outputs && dboxes && N > 0 && P > 0, "decode_score: bad arguments");
+    SSDHIP_REQUIRE(C == 21, "decode_score: built for C = 21");
+    int64_t total = (int64_t)N * P;
+    hipLaunchKernelGGL(decode_score_kernel<21>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, outputs, dboxes, P, total);
+    SSDHIP_CHECK_LAUNCH();
+    return SSDHIP_OK;
+}
+
+int ssdhip_calc_iou(const float* t, const float* s, int N, int T, int S, int rowt, int rows, float* iou, void* stream) {
+    SSDHIP_REQUIRE(t && s && iou && N > 0 && T > 0 && S > 0 && rowt >= 4 && rows >= 4, "calc_iou: bad arguments");
+    SSDHIP_REQUIRE(T <= 65535 && N <= 65535, "calc_iou: T and N must be <= 65535");
+    hipLaunchKernelGGL(calc_iou_kernel, dim3(cdiv(S, 256), T, N), dim3(256), 0, (hipStream_t)stream, t, s, T, S, rowt, rows, iou);
+    SSDHIP_CHECK_LAUNCH();
+    return SSDHIP_OK;
+}
+
+int ssdhip_nms(float* outputs, int N, int P, int C, float iou_thresh, uint8_t* keep, void* stream) {
+    SSDHIP_REQUIRE(outputs && N > 0 && P > 0 && C >= 2, "nms: bad arguments");
+    // LDS plan: idx16 (2P) + kept boxes (16P) + keep bits + misc must fit 160 KiB -> P <= 9000
+    SSDHIP_REQUIRE(P <= 9000, "nms: P <= 9000 (all-LDS kept list); larger prior sets need the global-list variant");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                NMS_LDS_BYTES) != hipSuccess) {
+            ssdhip_set_error("nms: cannot enable 160 KiB dynamic LDS");
+            return SSDHIP_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    int idx_bytes = ((2 * P + 15) / 16) * 16;
+    int keepbits_bytes = (((P + 31) / 32 + 3) / 4 * 4) * 4;
+    int kept_cap = (NMS_LDS_BYTES - NMS_MISC_BYTES - keepbits_bytes - idx_bytes) / 16;
+    SSDHIP_REQUIRE(kept_cap >= P, "nms: LDS plan does not fit");
+    hipLaunchKernelGGL(nms_kernel, dim3(N), dim3(NMS_THREADS), NMS_LDS_BYTES, (hipStream_t)stream, outputs, P, C, iou_thresh, keep,
+                       idx_bytes, kept_cap);
+    SSDHIP_CHECK_LAUNCH();
+    return SSDHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,364 @@
+"""Launch plan of the SSD300 forward / tail-backward on libssdhip.so.
+
+Replaces the ATen dispatch behind SSD.forward (model/ssd.py:86-106) and the autograd backward of the trainable tail
+(train.py:121).  Design (MI355X-first):
+  * NHWC fp32 activations, raw conv outputs `z` are the only materialised tensors; BatchNorm(train)+ReLU of layer L is
+    applied while layer L+1 (and its detector head) stage their input tiles, or fused into the max-pool pass;
+  * BN batch statistics come from per-block partials written by the conv epilogue (no extra pass over `z`);
+  * detector heads write straight into the (N, P, 4+C) output (zero-copy concat, ssd.py:103-104);
+  * the VGG part is frozen (ssd.py:31-32): no graph, no saved activations, no dgrad/wgrad for conv_1_1..conv_5_3;
+  * gradients land in one flat fp32 buffer (views per parameter) so data-parallel all-reduce is a few large RCCL calls.
+"""
+import ctypes
+
+import torch
+
+from .. import _lib
+from . import topology as T
+
+
+def _rup(v, m):
+    return (v + m - 1) // m * m
+
+
+class _ConvSpec:
+    def __init__(self, name, cin, cout, k, stride, pad, frozen, is_head=False):
+        self.name, self.cin, self.cout, self.k, self.stride, self.pad = name, cin, cout, k, stride, pad
+        self.frozen, self.is_head = frozen, is_head
+        self.cin_pad = 4 if cin == 3 else cin
+        self.KP = _rup(k * k * self.cin_pad, 32)
+        self.rows_pad = _rup(cout, 128)
+        # dgrad operand: rows = ci, k = tap * co_pad + co
+        self.co_pad = _rup(cout, 32)
+        self.KPd = k * k * self.co_pad
+        self.rows_pad_d = _rup(cin, 128)
+        self.packed = None
+        self.packed_key = None
+        self.packed_d = None
+        self.packed_d_key = None
+
+
+class _Stage:
+    """conv + bn (+ pool) (+ detector head) of the feature chain."""
+
+    def __init__(self, conv, bn_name, pool_pad, head, head_index):
+        self.conv, self.bn_name, self.pool_pad, self.head, self.head_index = conv, bn_name, pool_pad, head, head_index
+
+
+class Engine:
+    def __init__(self, module):
+        self.m = module                      # the SSD nn.Module (parameters / buffers live there)
+        self.lib = _lib.load()
+        self.nc = module.num_classes
+        self.row = self.nc + 4
+        plan = T.feature_plan()
+        heads = {h['tag']: (i, h) for i, h in enumerate(T.head_plan(self.nc))}
+        self.stages = []
+        i = 0
+        while i < len(plan):
+            l = plan[i]
+            assert l['kind'] == 'conv'
+            conv = _ConvSpec(l['name'], l['cin'], l['cout'], l['k'], l['stride'], l['pad'], l['frozen'])
+            bn = plan[i + 1]['name']
+            i += 3
+            pool_pad = None
+            if i < len(plan) and plan[i]['kind'] == 'pool':
+                pool_pad = plan[i]['pad']
+                i += 1
+            head, hidx = None, None
+            if l['tag'] in heads:
+                hidx, h = heads[l['tag']]
+                head = _ConvSpec(h['name'], h['cin'], h['cout'], 3, 1, 1, False, is_head=True)
+                head.anchors = h['anchors']
+            self.stages.append(_Stage(conv, bn, pool_pad, head, hidx))
+        self.tail_start = next(i for i, s in enumerate(self.stages) if not s.conv.frozen)
+        self._bufs = {}
+        self._bn = {}          # bn name -> dict(scale, shift, mean, invstd)
+        self._saved = None     # forward context consumed by backward
+        self._flat = None
+        self.dist_hook = None  # callable(flat_grad) for data-parallel all-reduce (parallel.py)
+
+    # ------------------------------------------------------------------------------------------------ helpers
+    def _weight(self, spec):
+        mod = (self.m.detectors if spec.is_head else self.m.features)[spec.name]
+        return mod.weight, mod.bias
+
+    def _pack(self, spec, dgrad=False):
+        w, _ = self._weight(spec)
+        _lib.require_gpu(w)
+        key = (w.data_ptr(), w._version, self.m._hip_epoch if not spec.frozen else 0)
+        if not dgrad:
+            if spec.packed is None or spec.packed.device != w.device:
+                spec.packed = torch.empty(spec.rows_pad * spec.KP, device=w.device, dtype=torch.float32)
+                spec.packed_key = None
+            if spec.packed_key != key:
+                _lib.check(self.lib.ssdhip_pack_conv_weight(_lib.ptr(w), _lib.ptr(spec.packed), spec.cout, spec.cin, spec.k, spec.k,
+                                                            spec.rows_pad, spec.cin_pad, spec.KP, 0, _lib.stream()), 'pack_conv_weight')
+                spec.packed_key = key
+            return spec.packed
+        if spec.packed_d is None or spec.packed_d.device != w.device:
+            spec.packed_d = torch.empty(spec.rows_pad_d * spec.KPd, device=w.device, dtype=torch.float32)
+            spec.packed_d_key = None
+        if spec.packed_d_key != key:
+            _lib.check(self.lib.ssdhip_pack_conv_weight(_lib.ptr(w), _lib.ptr(spec.packed_d), spec.cout, spec.cin, spec.k, spec.k,
+                                                        spec.rows_pad_d, spec.co_pad, spec.KPd, 1, _lib.stream()), 'pack_conv_weight')
+            spec.packed_d_key = key
+        return spec.packed_d
+
+    def _bn_state(self, name, c, dev):
+        st = self._bn.get(name)
+        if st is None or st['scale'].device != dev:
+            st = {k: torch.empty(c, device=dev, dtype=torch.float32) for k in ('scale', 'shift', 'mean', 'invstd')}
+            self._bn[name] = st
+        return st
+
+    def _geometry(self, H, W):
+        """Per-stage spatial sizes for an HxW input."""
+        geo, h, w = [], H, W
+        for s in self.stages:
+            c = s.conv
+            ho = (h + 2 * c.pad - c.k) // c.stride + 1
+            wo = (w + 2 * c.pad - c.k) // c.stride + 1
+            g = dict(hi=h, wi=w, ho=ho, wo=wo)
+            h, w = ho, wo
+            if s.pool_pad is not None:
+                h = (h + 2 * s.pool_pad - 2) // 2 + 1
+                w = (w + 2 * s.pool_pad - 2) // 2 + 1
+            g['ha'], g['wa'] = h, w      # activation size after the optional pool
+            geo.append(g)
+        return geo
+
+    def _buffers(self, N, H, W, dev):
+        key = (N, H, W, str(dev))
+        b = self._bufs.get(key)
+        if b is not None:
+            return b
+        geo = self._geometry(H, W)
+        f = dict(device=dev, dtype=torch.float32)
+        b = dict(geo=geo, x4=torch.empty(N, H, W, 4, **f), z=[], pooled=[])
+        max_partial, cmax = 0, 0
+        offs, p = [], 0
+        for s, g in zip(self.stages, geo):
+            b['z'].append(torch.empty(N, g['ho'], g['wo'], s.conv.cout, **f))
+            b['pooled'].append(torch.empty(N, g['ha'], g['wa'], s.conv.cout, **f) if s.pool_pad is not None else None)
+            M = N * g['ho'] * g['wo']
+            max_partial = max(max_partial, ((M + 63) // 64) * s.conv.cout * 2)
+            cmax = max(cmax, s.conv.cout)
+            if s.head is not None:
+                offs.append(p)
+                p += g['ha'] * g['wa'] * s.head.anchors
+        b['head_off'], b['P'] = offs, p
+        b['partial'] = torch.empty(max_partial, **f)
+        b['ws64'] = torch.empty(64 * cmax * 2, device=dev, dtype=torch.float64)
+        self._bufs[key] = b
+        return b
+
+    def _conv(self, spec, x, xs, y, y_batch_stride, N, hi, wi, ho, wo, stats, tile=0):
+        w = self._pack(spec)
+        _, bias = self._weight(spec)
+        p = _lib.ConvParams()
+        p.x, p.w, p.bias = x.data_ptr(), w.data_ptr(), (bias.data_ptr() if bias is not None else None)
+        p.in_scale = xs[0].data_ptr() if xs is not None else None
+        p.in_shift = xs[1].data_ptr() if xs is not None else None
+        p.y = y
+        p.stats = stats.data_ptr() if stats is not None else None
+        p.y_batch_stride = y_batch_stride
+        p.N, p.Hi, p.Wi, p.Cin = N, hi, wi, spec.cin_pad
+        p.Ho, p.Wo, p.Cout = ho, wo, spec.cout
+        p.R, p.S, p.stride, p.pad = spec.k, spec.k, spec.stride, spec.pad
+        p.KP, p.mode, p.accumulate, p.tile = spec.KP, 0, 0, tile
+        bm = self.lib.ssdhip_conv2d_block_m(ctypes.byref(p))
+        _lib.check(self.lib.ssdhip_conv2d_nhwc(ctypes.byref(p), _lib.stream()), f'conv2d {spec.name}')
+        return bm
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def forward(self, x, save):
+        _lib.require_gpu(x)
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError(f'expected (N, 3, H, W) input, got {tuple(x.shape)}')
+        x = _lib.f32c(x)
+        N, _, H, W = x.shape
+        dev = x.device
+        b = self._buffers(N, H, W, dev)
+        geo = b['geo']
+        training = self.m.training
+        out = torch.empty(N, b['P'], self.row, device=dev, dtype=torch.float32)
+        st = _lib.stream()
+        _lib.check(self.lib.ssdhip_normalize_nchw_to_nhwc4(_lib.ptr(x), _lib.ptr(b['x4']), N, H, W, st), 'normalize')
+        cur, cur_xs = b['x4'], None
+        acts = []            # per stage: (tensor, xform) that later layers read
+        nbt = []
+        for i, (s, g) in enumerate(zip(self.stages, geo)):
+            c = s.conv
+            bnm = self.m.features[s.bn_name]
+            z = b['z'][i]
+            M = N * g['ho'] * g['wo']
+            bst = self._bn_state(s.bn_name, c.cout, dev)
+            bm = self._conv(c, cur, cur_xs, z.data_ptr(), g['ho'] * g['wo'] * c.cout, N, g['hi'], g['wi'], g['ho'], g['wo'],
+                            b['partial'] if training else None)
+            if training:
+                track = bnm.track_running_stats and bnm.running_mean is not None
+                mom = 0.1 if bnm.momentum is None else bnm.momentum
+                _lib.check(self.lib.ssdhip_bn_finalize(_lib.ptr(b['partial']), (M + bm - 1) // bm, c.cout, M, _lib.ptr(bnm.weight),
+                                                       _lib.ptr(bnm.bias), _lib.ptr(bnm.running_mean) if track else None,
+                                                       _lib.ptr(bnm.running_var) if track else None, mom, bnm.eps,
+                                                       _lib.ptr(bst['scale']), _lib.ptr(bst['shift']), _lib.ptr(bst['mean']),
+                                                       _lib.ptr(bst['invstd']), _lib.ptr(b['ws64']), st), f'batch_norm {s.bn_name}')
+                if track and bnm.num_batches_tracked is not None:
+                    nbt.append(bnm.num_batches_tracked)
+            else:
+                _lib.check(self.lib.ssdhip_bn_fold_eval(_lib.ptr(bnm.weight), _lib.ptr(bnm.bias), _lib.ptr(bnm.running_mean),
+                                                        _lib.ptr(bnm.running_var), bnm.eps, c.cout, _lib.ptr(bst['scale']),
+                                                        _lib.ptr(bst['shift']), st), f'batch_norm(eval) {s.bn_name}')
+            if s.pool_pad is not None:
+                pooled = b['pooled'][i]
+                _lib.check(self.lib.ssdhip_bn_relu_pool(_lib.ptr(z), _lib.ptr(bst['scale']), _lib.ptr(bst['shift']), _lib.ptr(pooled),
+                                                        N, g['ho'], g['wo'], c.cout, 1, s.pool_pad, st), f'pool after {c.name}')
+                cur, cur_xs = pooled, None
+            else:
+                cur, cur_xs = z, (bst['scale'], bst['shift'])
+            acts.append((cur, cur_xs))
+            if s.head is not None:
+                off = b['head_off'][s.head_index]
+                self._conv(s.head, cur, cur_xs, out.data_ptr() + off * self.row * 4, b['P'] * self.row, N, g['ha'], g['wa'],
+                           g['ha'], g['wa'], None)
+        if nbt:
+            torch._foreach_add_(nbt, 1)
+        self._saved = dict(b=b, N=N, acts=acts, training=training) if save else None
+        return out
+
+    # ------------------------------------------------------------------------------------------------ backward
+    def grad_layout(self):
+        """(names, params, offsets, total): flat gradient buffer layout in SSD.train_params() order, 16-B aligned."""
+        names, params, offs, p = [], [], [], 0
+        for n, q in self.m.named_train_params():
+            names.append(n); params.append(q); offs.append(p)
+            p += _rup(q.numel(), 4)
+        return names, params, offs, p
+
+    def _flat_grad(self, dev):
+        names, params, offs, total = self.grad_layout()
+        if self._flat is None or self._flat['buf'].device != dev or self._flat['total'] != total:
+            self._flat = dict(buf=torch.zeros(total, device=dev, dtype=torch.float32), total=total, names=names, offs=offs)
+        views = {n: self._flat['buf'][o:o + q.numel()].view(q.shape) for n, q, o in zip(names, params, offs)}
+        return self._flat['buf'], views, params, names
+
+    def _bwd_buffers(self, sv):
+        b, N = sv['b'], sv['N']
+        if 'bwd' in b:
+            return b['bwd']
+        dev = b['x4'].device
+        f = dict(device=dev, dtype=torch.float32)
+        geo = b['geo']
+        bw = dict(da={}, dz={}, dyh={})
+        max_c, ws_bytes = 0, 0
+        for i in range(self.tail_start, len(self.stages)):
+            s, g = self.stages[i], geo[i]
+            bw['da'][i] = torch.empty(N, g['ho'], g['wo'], s.conv.cout, **f)
+            bw['dz'][i] = torch.empty(N, g['ho'], g['wo'], s.conv.cout, **f)
+            max_c = max(max_c, s.conv.cout)
+        for i, (s, g) in enumerate(zip(self.stages, geo)):
+            if s.head is not None:
+                bw['dyh'][i] = torch.zeros(N, g['ha'] * g['wa'], s.head.co_pad, **f)
+        bw['partial'] = torch.empty(512 * max_c * 2, **f)
+        bw['coef'] = torch.empty(max_c * 2, **f)
+        # wgrad split-K workspace: query every layer once
+        for i, (s, g) in enumerate(zip(self.stages, geo)):
+            for spec, (hi, wi, ho, wo) in ((s.conv, (g['hi'], g['wi'], g['ho'], g['wo'])), (s.head, (g['ha'], g['wa'], g['ha'], g['wa']))):
+                if spec is None or spec.frozen:
+                    continue
+                p = self._wgrad_params(spec, N, hi, wi, ho, wo)
+                ws_bytes = max(ws_bytes, self.lib.ssdhip_conv2d_wgrad_ws_bytes(ctypes.byref(p)))
+        bw['wgrad_ws'] = torch.empty((ws_bytes + 3) // 4, **f)
+        b['bwd'] = bw
+        return bw
+
+    def _wgrad_params(self, spec, N, hi, wi, ho, wo):
+        p = _lib.WgradParams()
+        p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout = N, hi, wi, spec.cin, ho, wo, spec.cout
+        p.R, p.S, p.stride, p.pad = spec.k, spec.k, spec.stride, spec.pad
+        p.dy_row = spec.co_pad if spec.is_head else spec.cout
+        p.dy_batch_stride = ho * wo * p.dy_row
+        return p
+
+    def _wgrad(self, spec, x, xs, dy, views, bw, N, hi, wi, ho, wo):
+        p = self._wgrad_params(spec, N, hi, wi, ho, wo)
+        prefix = ('detectors.' if spec.is_head else 'features.') + spec.name
+        p.x, p.dy = x.data_ptr(), dy.data_ptr()
+        p.in_scale = xs[0].data_ptr() if xs is not None else None
+        p.in_shift = xs[1].data_ptr() if xs is not None else None
+        p.dw_oihw = views[prefix + '.weight'].data_ptr()
+        p.dbias = views[prefix + '.bias'].data_ptr() if (prefix + '.bias') in views else None
+        p.ws = bw['wgrad_ws'].data_ptr()
+        _lib.check(self.lib.ssdhip_conv2d_wgrad(ctypes.byref(p), _lib.stream()), f'wgrad {spec.name}')
+
+    def _dgrad(self, spec, dy, dx, N, hdy, wdy, hin, win, accumulate):
+        w = self._pack(spec, dgrad=True)
+        p = _lib.ConvParams()
+        p.x, p.w, p.bias, p.in_scale, p.in_shift = dy.data_ptr(), w.data_ptr(), None, None, None
+        p.y, p.stats, p.y_batch_stride = dx.data_ptr(), None, hin * win * spec.cin
+        p.N, p.Hi, p.Wi, p.Cin = N, hdy, wdy, spec.co_pad
+        p.Ho, p.Wo, p.Cout = hin, win, spec.cin
+        p.R, p.S, p.stride, p.pad = spec.k, spec.k, spec.stride, spec.pad
+        p.KP, p.mode, p.accumulate, p.tile = spec.KPd, 1, int(accumulate), 0
+        _lib.check(self.lib.ssdhip_conv2d_nhwc(ctypes.byref(p), _lib.stream()), f'dgrad {spec.name}')
+
+    def backward(self, grad_out):
+        sv = self._saved
+        if sv is None:
+            raise RuntimeError('backward called without a saved forward (forward ran under no_grad or was already consumed)')
+        if not sv['training']:
+            raise RuntimeError('backward through eval-mode BatchNorm is not implemented (the reference never calls eval())')
+        self._saved = None
+        b, N, acts = sv['b'], sv['N'], sv['acts']
+        geo = b['geo']
+        _lib.require_gpu(grad_out)
+        grad_out = _lib.f32c(grad_out)
+        dev = grad_out.device
+        bw = self._bwd_buffers(sv)
+        flat, views, params, names = self._flat_grad(dev)
+        st = _lib.stream()
+        L = self.lib
+        # dense (N,P,row) gradient -> channel-padded per-head NHWC gradients
+        for i, (s, g) in enumerate(zip(self.stages, geo)):
+            if s.head is not None:
+                _lib.check(L.ssdhip_scatter_head_grad(_lib.ptr(grad_out), _lib.ptr(bw['dyh'][i]), N, b['P'], self.row,
+                                                      b['head_off'][s.head_index], g['ha'] * g['wa'], s.head.cout, s.head.co_pad, st),
+                           'scatter_head_grad')
+        # heads on frozen activations (det_4_3): weight gradient only
+        for i in range(self.tail_start):
+            s, g = self.stages[i], geo[i]
+            if s.head is not None:
+                x, xs = acts[i]
+                self._wgrad(s.head, x, xs, bw['dyh'][i], views, bw, N, g['ha'], g['wa'], g['ha'], g['wa'])
+        last = len(self.stages) - 1
+        for i in range(last, self.tail_start - 1, -1):
+            s, g = self.stages[i], geo[i]
+            c = s.conv
+            da, dz = bw['da'][i], bw['dz'][i]
+            x_act, x_xs = acts[i]                       # this stage's activation (input of its head / next conv)
+            if s.head is not None:
+                self._wgrad(s.head, x_act, x_xs, bw['dyh'][i], views, bw, N, g['ha'], g['wa'], g['ha'], g['wa'])
+                self._dgrad(s.head, bw['dyh'][i], da, N, g['ha'], g['wa'], g['ha'], g['wa'], accumulate=(i != last))
+            # BatchNorm(train) + ReLU backward: da -> dz, d gamma, d beta
+            bst = self._bn[s.bn_name]
+            M = N * g['ho'] * g['wo']
+            mb = max(1, min(512, (M + 127) // 128))
+            z = b['z'][i]
+            _lib.check(L.ssdhip_bn_relu_bwd_reduce(_lib.ptr(z), _lib.ptr(da), _lib.ptr(bst['scale']), _lib.ptr(bst['shift']),
+                                                   _lib.ptr(bst['mean']), _lib.ptr(bst['invstd']), M, c.cout, _lib.ptr(bw['partial']),
+                                                   mb, st), 'bn_relu_bwd_reduce')
+            _lib.check(L.ssdhip_bn_relu_bwd_finalize(_lib.ptr(bw['partial']), mb, c.cout, M,
+                                                     _lib.ptr(views[f'features.{s.bn_name}.weight']),
+                                                     _lib.ptr(views[f'features.{s.bn_name}.bias']), _lib.ptr(bw['coef']),
+                                                     _lib.ptr(b['ws64']), st), 'bn_relu_bwd_finalize')
+            _lib.check(L.ssdhip_bn_relu_bwd_apply(_lib.ptr(z), _lib.ptr(da), _lib.ptr(bst['scale']), _lib.ptr(bst['shift']),
+                                                  _lib.ptr(bst['mean']), _lib.ptr(bst['invstd']), _lib.ptr(bw['coef']), M, c.cout,
+                                                  _lib.ptr(dz), st), 'bn_relu_bwd_apply')
+            xin, xin_xs = acts[i - 1]
+            self._wgrad(c, xin, xin_xs, dz, views, bw, N, g['hi'], g['wi'], g['ho'], g['wo'])
+            if i > self.tail_start:
+                self._dgrad(c, dz, bw['da'][i - 1], N, g['ho'], g['wo'], g['hi'], g['wi'], accumulate=False)
+        if self.dist_hook is not None:
+            self.dist_hook(flat)
+        return [views[n] for n in names], params

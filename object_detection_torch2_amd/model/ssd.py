@@ -1,0 +1,241 @@
+"""`SSD` with the reference's module API (src/model/ssd.py:8-328), executed by hand-written HIP kernels on MI355X.
+
+Kept from the reference: constructor signature; `.num_classes`, `.default_bboxes` (CPU fp32 (P,4)),
+`.normalize`, `.features` / `.detectors` ModuleDicts with the same keys, parameter shapes and state_dict layout (173
+entries, OIHW fp32, so weights.pth files interchange); `.forward`, `.loss`, `.train_params`.
+
+Deliberate deviations, all recorded in DESIGN.md:
+  * forward implements the documented contract (N, P, 4+C) (ssd.py:93); the literal code never fires a detector
+    (ssd.py:102 tests a features key against detector keys) and returns (N, 0, 4+C);
+  * no torch.hub fetch (vgg16.py:68): without a local VGG16 weights file the frozen backbone is kaiming-initialised;
+  * tensors must live on the GPU: there is no CPU fallback (RuntimeError), the CPU restatement is test-only (oracle/).
+"""
+import pathlib
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from . import topology as T
+from .engine import Engine
+
+
+class _SSDForward(torch.autograd.Function):
+    """outputs = net(x).  Inputs: x and the trainable parameters (so autograd routes their gradients);
+    backward runs the hand-written tail backward and returns views of the flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        ctx.net = net
+        ctx.token = object()
+        net._engine_token = ctx.token
+        return net._engine().forward(x, save=True)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        net = ctx.net
+        if net._engine_token is not ctx.token:
+            raise RuntimeError('SSD backward: a newer forward replaced the saved activations of this graph '
+                               '(one live training graph per module)')
+        eng = net._engine()
+        # p.grad may alias the flat buffer from the previous step (autograd steals the views); keep "+=" semantics
+        flat = eng._flat['buf'] if eng._flat is not None else None
+        alias = flat is not None and any(p.grad is not None and flat.data_ptr() <= p.grad.data_ptr() < flat.data_ptr() + flat.numel() * 4
+                                         for _, p in net.named_train_params())
+        old = flat.clone() if alias else None
+        grads, _ = eng.backward(grad_out)
+        if alias:
+            new = eng._flat['buf'].clone()
+            eng._flat['buf'].copy_(old)
+            names, params, offs, _ = eng.grad_layout()
+            grads = [new[o:o + q.numel()].view(q.shape) for q, o in zip(params, offs)]
+        return (None, None) + tuple(grads)
+
+
+class _MultiBoxLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, outputs, targets, dboxes, alpha, threshold):
+        lib = _lib.load()
+        N, P, row = outputs.shape
+        G = targets.shape[1]
+        dev = outputs.device
+        terms = torch.empty(3, N, P, device=dev, dtype=torch.float32)
+        cnt = torch.empty(N, device=dev, dtype=torch.int32)
+        sel = torch.empty(N, 8, device=dev, dtype=torch.float32)
+        loss = torch.empty(1, device=dev, dtype=torch.float32)
+        _lib.check(lib.ssdhip_multibox_loss_fwd(_lib.ptr(outputs), _lib.ptr(targets), _lib.ptr(dboxes), N, P, G, row - 4,
+                                                float(alpha), float(threshold), _lib.ptr(terms), _lib.ptr(cnt), _lib.ptr(sel),
+                                                _lib.ptr(loss), _lib.stream()), 'SSD.loss')
+        ctx.save_for_backward(outputs, targets, dboxes, terms, sel)
+        ctx.alpha, ctx.threshold = float(alpha), float(threshold)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        outputs, targets, dboxes, terms, sel = ctx.saved_tensors
+        N, P, row = outputs.shape
+        G = targets.shape[1]
+        grad = torch.empty_like(outputs)
+        g = _lib.f32c(grad_loss).reshape(1)
+        _lib.check(_lib.load().ssdhip_multibox_loss_bwd(_lib.ptr(outputs), _lib.ptr(targets), _lib.ptr(dboxes), N, P, G, row - 4,
+                                                        ctx.alpha, ctx.threshold, _lib.ptr(terms), _lib.ptr(sel), _lib.ptr(g),
+                                                        _lib.ptr(grad), _lib.stream()), 'SSD.loss backward')
+        return grad, None, None, None, None
+
+
+class SSD(nn.Module):
+    def __init__(self, num_classes: int, weights_path: pathlib.Path = None, weights_path_vgg16: pathlib.Path = None):
+        """Same arguments as the reference (ssd.py:9).  weights_path_vgg16: local VGG16 state-dict (the reference's
+        vgg16.py:64-66 branch); its `features.N.*` entries initialise the frozen backbone."""
+        super(SSD, self).__init__()
+        self.num_classes = num_classes
+        self._hip_epoch = 0
+        self._eng = None
+        self._engine_token = None
+        self._default_bboxes = None      # generated lazily by the HIP kernel (first access needs the GPU)
+
+        features = nn.ModuleDict()
+        for l in T.feature_plan():
+            if l['kind'] == 'conv':
+                m = nn.Conv2d(in_channels=l['cin'], out_channels=l['cout'], kernel_size=l['k'], stride=l['stride'], padding=l['pad'])
+            elif l['kind'] == 'bn':
+                m = nn.BatchNorm2d(l['c'])
+            elif l['kind'] == 'act':
+                m = nn.ReLU(inplace=True)
+            else:
+                m = nn.MaxPool2d(kernel_size=2, stride=2, padding=l['pad'])
+            if l.get('frozen'):
+                for p in m.parameters():
+                    p.requires_grad = False          # ssd.py:31-32
+            features[l['name']] = m
+        self.features = features
+        self.detectors = nn.ModuleDict({
+            h['name']: nn.Conv2d(in_channels=h['cin'], out_channels=h['cout'], kernel_size=3, padding=1) for h in T.head_plan(num_classes)})
+
+        self._initialize_weights()
+        if weights_path_vgg16 and pathlib.Path(weights_path_vgg16).exists():
+            self._load_vgg16(pathlib.Path(weights_path_vgg16))
+        if weights_path and pathlib.Path(weights_path).exists():
+            print('weights loaded.')
+            self.load_state_dict(torch.load(pathlib.Path(weights_path).as_posix(), weights_only=True))
+
+    # ---- construction helpers ------------------------------------------------------------------------------
+    def _initialize_weights(self):
+        """ssd.py:135-158 for extras + detectors.  The frozen VGG part gets the same kaiming init here because the
+        reference's pretrained fetch (vgg16.py:68) is unavailable offline; load real weights via weights_path*."""
+        for m in list(self.features.values()) + list(self.detectors.values()):
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _load_vgg16(self, path):
+        """Map a reference VGG16 state-dict (`features.<idx>.*`, vgg16.py:25-39) onto conv_L_i / bn_L_i."""
+        sd = torch.load(path.as_posix(), weights_only=True)
+        own = self.state_dict()
+        idx, stage, sub = 0, 1, 1
+        with torch.no_grad():
+            for v in T.VGG_CFG:
+                if isinstance(v, str):
+                    idx, stage, sub = idx + 1, stage + 1, 1
+                    continue
+                for suffix in ('weight', 'bias'):
+                    own[f'features.conv_{stage}_{sub}.{suffix}'].copy_(sd[f'features.{idx}.{suffix}'])
+                for suffix in ('weight', 'bias', 'running_mean', 'running_var', 'num_batches_tracked'):
+                    own[f'features.bn_{stage}_{sub}.{suffix}'].copy_(sd[f'features.{idx + 1}.{suffix}'])
+                idx, sub = idx + 3, sub + 1
+        print('weights loaded.')
+
+    @property
+    def default_bboxes(self) -> torch.Tensor:
+        if self._default_bboxes is None:
+            self._default_bboxes = self._get_default_bboxes()
+        return self._default_bboxes
+
+    def _get_default_bboxes(self) -> torch.Tensor:
+        """(P, 4) CPU fp32 default boxes (ssd.py:108-133), generated by the HIP kernel when a GPU is present.
+        Callers move it with `.to(device)` like the reference (train.py:81)."""
+        if not torch.cuda.is_available():
+            raise RuntimeError('SSD needs an MI355X: default boxes are generated by libssdhip.so (no CPU fallback)')
+        return self.default_bboxes_on(torch.device('cuda', torch.cuda.current_device())).cpu()
+
+    @staticmethod
+    def default_bboxes_on(device) -> torch.Tensor:
+        import ctypes
+        maps = (ctypes.c_int32 * (3 * len(T.BOX_MAPS)))(*[v for m in T.BOX_MAPS for v in m])
+        out = torch.empty(T.num_priors(), 4, device=device, dtype=torch.float32)
+        with torch.cuda.device(device):
+            _lib.check(_lib.load().ssdhip_default_boxes(_lib.ptr(out), maps, len(T.BOX_MAPS), T.S_MIN, T.S_MAX, _lib.stream()),
+                       'default_boxes')
+        return out
+
+    def normalize(self, x: torch.Tensor) -> torch.Tensor:
+        """vgg16.py:103-115 as a stand-alone op (the forward fuses it with the NHWC conversion)."""
+        _lib.require_gpu(x)
+        x = _lib.f32c(x)
+        N, _, H, W = x.shape
+        y = torch.empty(N, H, W, 4, device=x.device, dtype=torch.float32)
+        _lib.check(_lib.load().ssdhip_normalize_nchw_to_nhwc4(_lib.ptr(x), _lib.ptr(y), N, H, W, _lib.stream()), 'normalize')
+        return y[..., :3].permute(0, 3, 1, 2)
+
+    # ---- reference API -------------------------------------------------------------------------------------
+    def _engine(self) -> Engine:
+        if self._eng is None:
+            self._eng = Engine(self)
+        return self._eng
+
+    def hip_weights_changed(self):
+        """Tell the engine that trainable weights were updated outside torch's version counter (FusedAdam)."""
+        self._hip_epoch += 1
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """(N, 3, 300, 300) float[0,1] -> (N, P, 4 + C) on x.device (ssd.py:86-106, documented contract)."""
+        _lib.require_gpu(x)
+        params = [p for _, p in self.named_train_params()]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return _SSDForward.apply(self, x, *params)
+        return self._engine().forward(x, save=False)
+
+    def named_train_params(self):
+        is_vgg = True
+        for name, layer in self.features.items():
+            if name == 'conv_6_1':
+                is_vgg = False
+            if is_vgg:
+                continue
+            for pn, param in layer.named_parameters():
+                yield f'features.{name}.{pn}', param
+        for name, layer in self.detectors.items():
+            for pn, param in layer.named_parameters():
+                yield f'detectors.{name}.{pn}', param
+
+    def train_params(self):
+        """ssd.py:160-179: features from conv_6_1 on, then the detectors."""
+        for _, p in self.named_train_params():
+            yield p
+
+    def loss(self, outputs: torch.Tensor, targets: torch.Tensor, default_bboxes: torch.Tensor, a: int = 1) -> torch.Tensor:
+        """MultiBox loss (ssd.py:181-229): IoU>0.25 multi-match, SmoothL1 + softmax CE, 3:1 hard-negative mining by the
+        (k+1)-th largest value, per-image 1/pos normalisation, batch mean.  0-dim tensor with grad."""
+        _lib.require_gpu(outputs, targets, default_bboxes)
+        if outputs.dim() != 3 or targets.dim() != 3 or outputs.shape[0] != targets.shape[0] or outputs.shape[2] != targets.shape[2]:
+            raise ValueError(f'loss: outputs {tuple(outputs.shape)} and targets {tuple(targets.shape)} do not match (N, *, 4 + C)')
+        if tuple(default_bboxes.shape) != (outputs.shape[1], 4):
+            raise ValueError(f'loss: default_bboxes must be ({outputs.shape[1]}, 4), got {tuple(default_bboxes.shape)}')
+        out = outputs if (outputs.is_contiguous() and outputs.dtype == torch.float32) else _lib.f32c(outputs)
+        return _MultiBoxLoss.apply(out, _lib.f32c(targets), _lib.f32c(default_bboxes), a, T.MATCH_THRESHOLD)
+
+    def _match(self, gt: torch.Tensor, df: torch.Tensor, threshold: float = 0.25) -> torch.Tensor:
+        """(N,G,>=4),(P,4) -> (N,P,G) bool match mask (ssd.py:231-250), bit-exact."""
+        _lib.require_gpu(gt, df)
+        gt, df = _lib.f32c(gt), _lib.f32c(df)
+        N, G, row = gt.shape
+        P = df.shape[0]
+        mask = torch.empty(N, P, G, device=gt.device, dtype=torch.uint8)
+        if G > 0:
+            _lib.check(_lib.load().ssdhip_match_mask(_lib.ptr(gt), _lib.ptr(df), N, P, G, row, float(threshold), _lib.ptr(mask),
+                                                     _lib.stream()), '_match')
+        return mask.bool()

@@ -1,0 +1,50 @@
+"""SSD300 / VGG16-bn topology as data (what the reference builds imperatively in model/vgg16.py:25-37 and
+model/ssd.py:28-77, 118).  Shared by the nn.Module shell (state_dict layout) and the HIP engine (launch plan)."""
+
+# VGG16-bn `features` cfg (vgg16.py:25): ints = conv3x3(p1)+BN+ReLU, 'M' = MaxPool(2,2), 'M_P' = MaxPool(2,2,padding=1)
+VGG_CFG = (64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M_P', 512, 512, 512, 'M', 512, 512, 512, 'M_P')
+# extras (ssd.py:49-54): per stage a list of (kernel, cout, stride, pad)
+EXTRA_CFG = (((3, 1024, 1, 1),), ((1, 1024, 1, 0),), ((1, 256, 1, 0), (3, 512, 2, 1)), ((1, 128, 1, 0), (3, 256, 2, 1)),
+             ((1, 128, 1, 0), (3, 256, 1, 0)), ((1, 128, 1, 0), (3, 256, 1, 0)))
+# detectors (ssd.py:70-77): (source activation tag, cin, anchors per cell)
+HEAD_CFG = (('4_3', 512, 4), ('7_1', 1024, 6), ('8_2', 512, 6), ('9_2', 256, 6), ('10_2', 256, 4), ('11_2', 256, 4))
+# default-box grid (ssd.py:118) and scales (ssd.py:114)
+BOX_MAPS = ((38, 38, 4), (19, 19, 6), (10, 10, 6), (5, 5, 6), (3, 3, 4), (1, 1, 4))
+S_MIN, S_MAX = 0.2, 0.9
+MATCH_THRESHOLD = 0.25      # ssd.py:231
+NMS_IOU_THRESHOLD = 0.5     # utils.py:80
+
+
+def feature_plan():
+    """Ordered list of feature layers.  conv: name,cin,cout,k,stride,pad,frozen; bn: name,c,frozen; act; pool: name,pad.
+    pool_5 is dropped and every VGG layer is frozen (ssd.py:31-41)."""
+    plan, cin, stage, sub = [], 3, 1, 1
+    for v in VGG_CFG:
+        if isinstance(v, str):
+            if stage < 5:
+                plan.append(dict(kind='pool', name=f'pool_{stage}', pad=1 if v == 'M_P' else 0))
+            stage, sub = stage + 1, 1
+            continue
+        tag = f'{stage}_{sub}'
+        plan.append(dict(kind='conv', name=f'conv_{tag}', tag=tag, cin=cin, cout=v, k=3, stride=1, pad=1, frozen=True))
+        plan.append(dict(kind='bn', name=f'bn_{tag}', tag=tag, c=v, frozen=True))
+        plan.append(dict(kind='act', name=f'act_{tag}', tag=tag))
+        cin, sub = v, sub + 1
+    for group in EXTRA_CFG:
+        sub = 1
+        for (k, v, s, p) in group:
+            tag = f'{stage}_{sub}'
+            plan.append(dict(kind='conv', name=f'conv_{tag}', tag=tag, cin=cin, cout=v, k=k, stride=s, pad=p, frozen=False))
+            plan.append(dict(kind='bn', name=f'bn_{tag}', tag=tag, c=v, frozen=False))
+            plan.append(dict(kind='act', name=f'act_{tag}', tag=tag))
+            cin, sub = v, sub + 1
+        stage += 1
+    return plan
+
+
+def head_plan(num_classes):
+    return [dict(name=f'det_{t}', tag=t, cin=c, anchors=a, cout=a * (num_classes + 4)) for t, c, a in HEAD_CFG]
+
+
+def num_priors():
+    return sum(m * n * a for m, n, a in BOX_MAPS)

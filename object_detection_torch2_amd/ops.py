@@ -1,0 +1,152 @@
+"""Functional (allocate-and-call) wrappers over single libssdhip.so entry points.  The engine drives the same entry
+points with pre-allocated buffers; these exist for per-kernel parity tests, profiling and ad-hoc use."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _rup(v, m):
+    return (v + m - 1) // m * m
+
+
+def pack_weight(w_oihw, mode=0):
+    """OIHW -> packed implicit-GEMM operand.  Returns (packed, KP, inner_pad)."""
+    _lib.require_gpu(w_oihw)
+    w = _lib.f32c(w_oihw)
+    cout, cin, k, _ = w.shape
+    if mode == 0:
+        inner = 4 if cin == 3 else cin
+        rows = _rup(cout, 128)
+    else:
+        inner = _rup(cout, 32)
+        rows = _rup(cin, 128)
+    KP = _rup(k * k * inner, 32)
+    packed = torch.empty(rows * KP, device=w.device, dtype=torch.float32)
+    _lib.check(_lib.load().ssdhip_pack_conv_weight(_lib.ptr(w), _lib.ptr(packed), cout, cin, k, k, rows, inner, KP, mode, _lib.stream()),
+               'pack_conv_weight')
+    return packed, KP, inner
+
+
+def conv2d_nhwc(x, w_oihw, bias=None, stride=1, pad=0, in_scale=None, in_shift=None, want_stats=False, tile=0):
+    """x (N,H,W,Cin_pad) fp32 NHWC -> (z (N,Ho,Wo,Cout), stats or None).  stats: (MB, Cout, 2) partial sums."""
+    _lib.require_gpu(x, w_oihw)
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    cout, cin, k, _ = w_oihw.shape
+    packed, KP, inner = pack_weight(w_oihw, 0)
+    if inner != C:
+        raise ValueError(f'input has {C} channels, weights expect {inner} (pad the 3-channel image to 4)')
+    ho, wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    z = torch.empty(N, ho, wo, cout, device=x.device, dtype=torch.float32)
+    p = _lib.ConvParams()
+    p.x, p.w, p.bias = x.data_ptr(), packed.data_ptr(), (bias.data_ptr() if bias is not None else None)
+    p.in_scale = in_scale.data_ptr() if in_scale is not None else None
+    p.in_shift = in_shift.data_ptr() if in_shift is not None else None
+    p.y, p.y_batch_stride = z.data_ptr(), ho * wo * cout
+    p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout = N, H, W, C, ho, wo, cout
+    p.R, p.S, p.stride, p.pad, p.KP, p.mode, p.accumulate, p.tile = k, k, stride, pad, KP, 0, 0, tile
+    stats = None
+    if want_stats:
+        bm = lib.ssdhip_conv2d_block_m(ctypes.byref(p))
+        stats = torch.empty((N * ho * wo + bm - 1) // bm, cout, 2, device=x.device, dtype=torch.float32)
+        p.stats = stats.data_ptr()
+    _lib.check(lib.ssdhip_conv2d_nhwc(ctypes.byref(p), _lib.stream()), 'conv2d_nhwc')
+    return z, stats
+
+
+def conv2d_dgrad(dy, w_oihw, in_hw, stride=1, pad=0, accumulate_into=None, tile=0):
+    """dy (N,Ho,Wo,Cout_pad) -> dx (N,Hi,Wi,Cin): data gradient of conv2d(x, w, stride, pad)."""
+    _lib.require_gpu(dy, w_oihw)
+    N, ho, wo, cdy = dy.shape
+    cout, cin, k, _ = w_oihw.shape
+    packed, KP, inner = pack_weight(w_oihw, 1)
+    if inner != cdy:
+        raise ValueError(f'dy has {cdy} channels, expected {inner} (Cout padded to a multiple of 32)')
+    hi, wi = in_hw
+    dx = accumulate_into if accumulate_into is not None else torch.empty(N, hi, wi, cin, device=dy.device, dtype=torch.float32)
+    p = _lib.ConvParams()
+    p.x, p.w, p.y, p.y_batch_stride = dy.data_ptr(), packed.data_ptr(), dx.data_ptr(), hi * wi * cin
+    p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout = N, ho, wo, cdy, hi, wi, cin
+    p.R, p.S, p.stride, p.pad, p.KP, p.mode, p.accumulate, p.tile = k, k, stride, pad, KP, 1, int(accumulate_into is not None), tile
+    _lib.check(_lib.load().ssdhip_conv2d_nhwc(ctypes.byref(p), _lib.stream()), 'conv2d_dgrad')
+    return dx
+
+
+def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, in_scale=None, in_shift=None, want_bias=True):
+    """x (N,Hi,Wi,Cin), dy (N,Ho,Wo,dy_row>=Cout) -> (dW OIHW, db or None)."""
+    _lib.require_gpu(x, dy)
+    lib = _lib.load()
+    cout, cin, k, _ = w_shape
+    N, hi, wi, _ = x.shape
+    _, ho, wo, row = dy.shape
+    dw = torch.empty(w_shape, device=x.device, dtype=torch.float32)
+    db = torch.empty(cout, device=x.device, dtype=torch.float32) if want_bias else None
+    p = _lib.WgradParams()
+    p.x, p.dy = x.data_ptr(), dy.data_ptr()
+    p.in_scale = in_scale.data_ptr() if in_scale is not None else None
+    p.in_shift = in_shift.data_ptr() if in_shift is not None else None
+    p.dw_oihw, p.dbias = dw.data_ptr(), (db.data_ptr() if db is not None else None)
+    p.dy_batch_stride = ho * wo * row
+    p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout = N, hi, wi, cin, ho, wo, cout
+    p.R, p.S, p.stride, p.pad, p.dy_row = k, k, stride, pad, row
+    ws = torch.empty((lib.ssdhip_conv2d_wgrad_ws_bytes(ctypes.byref(p)) + 3) // 4, device=x.device, dtype=torch.float32)
+    p.ws = ws.data_ptr()
+    _lib.check(lib.ssdhip_conv2d_wgrad(ctypes.byref(p), _lib.stream()), 'conv2d_wgrad')
+    return dw, db
+
+
+def bn_finalize(stats, count, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+    """(MB,C,2) partials -> dict(scale, shift, mean, invstd); updates running stats in place like nn.BatchNorm2d."""
+    _lib.require_gpu(stats, gamma, beta)
+    MB, C, _ = stats.shape
+    dev = stats.device
+    out = {k: torch.empty(C, device=dev, dtype=torch.float32) for k in ('scale', 'shift', 'mean', 'invstd')}
+    ws = torch.empty(64 * C * 2, device=dev, dtype=torch.float64)
+    _lib.check(_lib.load().ssdhip_bn_finalize(_lib.ptr(stats), MB, C, int(count), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean),
+                                              _lib.ptr(running_var), momentum, eps, _lib.ptr(out['scale']), _lib.ptr(out['shift']),
+                                              _lib.ptr(out['mean']), _lib.ptr(out['invstd']), _lib.ptr(ws), _lib.stream()), 'batch_norm')
+    return out
+
+
+def bn_relu_pool(z, scale, shift, pool=False, pool_pad=0):
+    _lib.require_gpu(z, scale, shift)
+    N, H, W, C = z.shape
+    if pool:
+        ho, wo = (H + 2 * pool_pad - 2) // 2 + 1, (W + 2 * pool_pad - 2) // 2 + 1
+    else:
+        ho, wo = H, W
+    y = torch.empty(N, ho, wo, C, device=z.device, dtype=torch.float32)
+    _lib.check(_lib.load().ssdhip_bn_relu_pool(_lib.ptr(z), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(y), N, H, W, C, int(pool), pool_pad,
+                                               _lib.stream()), 'bn_relu_pool')
+    return y
+
+
+def bn_relu_bwd(z, da, st):
+    """Backward of relu(bn_train(z)): returns (dz, dgamma, dbeta).  st: dict from bn_finalize."""
+    lib = _lib.load()
+    C = z.shape[-1]
+    M = z.numel() // C
+    dev = z.device
+    mb = max(1, min(512, (M + 127) // 128))
+    partial = torch.empty(mb, C, 2, device=dev, dtype=torch.float32)
+    coef = torch.empty(C, 2, device=dev, dtype=torch.float32)
+    ws = torch.empty(64 * C * 2, device=dev, dtype=torch.float64)
+    dgamma = torch.empty(C, device=dev, dtype=torch.float32)
+    dbeta = torch.empty(C, device=dev, dtype=torch.float32)
+    dz = torch.empty_like(z)
+    s = _lib.stream()
+    args = (_lib.ptr(z), _lib.ptr(da), _lib.ptr(st['scale']), _lib.ptr(st['shift']), _lib.ptr(st['mean']), _lib.ptr(st['invstd']))
+    _lib.check(lib.ssdhip_bn_relu_bwd_reduce(*args, M, C, _lib.ptr(partial), mb, s), 'bn_relu_bwd_reduce')
+    _lib.check(lib.ssdhip_bn_relu_bwd_finalize(_lib.ptr(partial), mb, C, M, _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(coef), _lib.ptr(ws), s),
+               'bn_relu_bwd_finalize')
+    _lib.check(lib.ssdhip_bn_relu_bwd_apply(*args, _lib.ptr(coef), M, C, _lib.ptr(dz), s), 'bn_relu_bwd_apply')
+    return dz, dgamma, dbeta
+
+
+def to_nhwc(x_nchw, pad_to=None):
+    x = x_nchw.permute(0, 2, 3, 1).contiguous()
+    if pad_to and x.shape[-1] < pad_to:
+        x = torch.cat([x, x.new_zeros(*x.shape[:-1], pad_to - x.shape[-1])], dim=-1).contiguous()
+    return x

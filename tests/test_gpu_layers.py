@@ -1,0 +1,170 @@
+"""GPU parity of the dense layers: HIP conv (fwd / dgrad / wgrad, fused BN+ReLU input transform, BN statistics from
+the epilogue), BN finalize, BN+ReLU+pool, BN+ReLU backward -- against plain torch fp32 CPU ops (the third-party
+arithmetic the reference delegates to).  Tolerances are stated per test (fp32, accumulation-order differences only)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def rel_err(a, b):
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+
+
+# (N, H, W, Cin, Cout, k, stride, pad, tile)
+CONV_CASES = [
+    (2, 19, 19, 64, 128, 3, 1, 1, 0),        # generic 3x3
+    (2, 19, 19, 64, 128, 3, 1, 1, 128128),
+    (2, 19, 19, 64, 128, 3, 1, 1, 128064),
+    (2, 19, 19, 64, 128, 3, 1, 1, 64128),
+    (2, 19, 19, 64, 128, 3, 1, 1, 64064),
+    (3, 21, 17, 3, 64, 3, 1, 1, 0),          # conv_1_1 style: RGB padded to 4 channels, ragged M
+    (2, 19, 19, 128, 256, 1, 1, 0, 0),       # 1x1 (conv_7_1 style)
+    (2, 19, 19, 64, 96, 3, 2, 1, 0),         # stride 2 (conv_8_2 style), Cout not a tile multiple
+    (2, 5, 5, 32, 64, 3, 1, 0, 0),           # pad 0 (conv_10_2 style)
+    (2, 3, 3, 32, 64, 3, 1, 0, 0),           # 3 -> 1 (conv_11_2 style)
+    (2, 10, 10, 64, 150, 3, 1, 1, 0),        # detector head: Cout = 6 * 25
+    (1, 38, 38, 512, 100, 3, 1, 1, 0),       # det_4_3 shape: K = 4608
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_forward(case):
+    from object_detection_torch2_amd import ops
+    N, H, W, cin, cout, k, stride, pad, tile = case
+    x = rnd(N, cin, H, W, seed=1)
+    w = rnd(cout, cin, k, k, seed=2, scale=(2.0 / (cin * k * k)) ** 0.5)
+    b = rnd(cout, seed=3)
+    ref = F.conv2d(x, w, b, stride=stride, padding=pad)
+    xg = ops.to_nhwc(x.to(DEV), pad_to=4 if cin == 3 else None)
+    z, stats = ops.conv2d_nhwc(xg, w.to(DEV), b.to(DEV), stride=stride, pad=pad, want_stats=True, tile=tile)
+    got = z.permute(0, 3, 1, 2).cpu()
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < 2e-5                                  # fp32, K <= 4608
+    # epilogue statistics: per-channel sum and sum of squares over all pixels
+    s = stats.sum(dim=0).cpu()
+    assert torch.allclose(s[:, 0], ref.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(s[:, 1], (ref * ref).sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3)
+    # bit-reproducible replay
+    z2, _ = ops.conv2d_nhwc(xg, w.to(DEV), b.to(DEV), stride=stride, pad=pad, want_stats=True, tile=tile)
+    assert torch.equal(z, z2)
+
+
+def test_conv_fused_input_transform_and_padding():
+    """a = relu(z*scale+shift) applied while staging; zero padding must be applied AFTER the transform."""
+    from object_detection_torch2_amd import ops
+    N, H, W, cin, cout = 2, 12, 12, 64, 64
+    zprev = rnd(N, cin, H, W, seed=4)
+    scale, shift = rnd(cin, seed=5), rnd(cin, seed=6) + 0.5         # shift > 0 makes a wrong padding order visible
+    w = rnd(cout, cin, 3, 3, seed=7, scale=0.05)
+    a = F.relu(zprev * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    ref = F.conv2d(a, w, None, padding=1)
+    z, _ = ops.conv2d_nhwc(ops.to_nhwc(zprev.to(DEV)), w.to(DEV), None, pad=1, in_scale=scale.to(DEV), in_shift=shift.to(DEV))
+    assert rel_err(z.permute(0, 3, 1, 2).cpu(), ref) < 2e-5
+
+
+def test_batchnorm_train_pipeline_and_pool():
+    """conv epilogue partials -> bn_finalize -> BN+ReLU(+MaxPool(2,2,pad)) vs nn.BatchNorm2d(train) + F.max_pool2d."""
+    from object_detection_torch2_amd import ops
+    N, H, W, cin, cout = 4, 15, 15, 32, 64
+    x = rnd(N, cin, H, W, seed=8)
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1)
+    bn = torch.nn.BatchNorm2d(cout)
+    with torch.no_grad():
+        bn.weight.copy_(rnd(cout, seed=9)); bn.bias.copy_(rnd(cout, seed=10))
+    bn.train()
+    with torch.no_grad():
+        zr = conv(x)
+        yr = F.relu(bn(zr))
+    z, stats = ops.conv2d_nhwc(ops.to_nhwc(x.to(DEV)), conv.weight.detach().to(DEV), conv.bias.detach().to(DEV), pad=1, want_stats=True)
+    rm, rv = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV)
+    st = ops.bn_finalize(stats, N * H * W, bn.weight.detach().to(DEV), bn.bias.detach().to(DEV), rm, rv)
+    assert torch.allclose(rm.cpu(), bn.running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(rv.cpu(), bn.running_var, rtol=1e-5, atol=1e-6)
+    y = ops.bn_relu_pool(z, st['scale'], st['shift'])
+    assert (y.permute(0, 3, 1, 2).cpu() - yr).abs().max() < 1e-4
+    for pad in (0, 1):
+        yp = ops.bn_relu_pool(z, st['scale'], st['shift'], pool=True, pool_pad=pad)
+        ref = F.max_pool2d(yr, 2, 2, padding=pad)
+        assert yp.shape == (N, ref.shape[2], ref.shape[3], cout)
+        assert (yp.permute(0, 3, 1, 2).cpu() - ref).abs().max() < 1e-4
+    with pytest.raises(ValueError, match='more than 1 value per channel'):
+        ops.bn_finalize(stats[:1], 1, bn.weight.detach().to(DEV), bn.bias.detach().to(DEV))
+
+
+# (N, Hi, Wi, Cin, Cout, k, stride, pad)
+BWD_CASES = [
+    (2, 19, 19, 128, 256, 1, 1, 0),     # conv_8_1 style
+    (2, 19, 19, 128, 256, 3, 2, 1),     # conv_8_2 style (stride 2, odd input)
+    (2, 10, 10, 128, 256, 3, 2, 1),     # conv_9_2 style (stride 2, even input)
+    (2, 5, 5, 128, 256, 3, 1, 0),       # conv_10_2
+    (2, 3, 3, 128, 256, 3, 1, 0),       # conv_11_2
+    (2, 19, 19, 128, 150, 3, 1, 1),     # detector head: dy channels padded 150 -> 160
+    (3, 10, 10, 256, 100, 3, 1, 1),     # detector head: 100 -> 128
+]
+
+
+@pytest.mark.parametrize('case', BWD_CASES)
+def test_conv_dgrad_wgrad(case):
+    from object_detection_torch2_amd import ops
+    N, H, W, cin, cout, k, stride, pad = case
+    x = rnd(N, cin, H, W, seed=11).requires_grad_(True)
+    w = rnd(cout, cin, k, k, seed=12, scale=0.05).requires_grad_(True)
+    b = torch.zeros(cout, requires_grad=True)
+    y = F.conv2d(x, w, b, stride=stride, padding=pad)
+    dy = rnd(*y.shape, seed=13)
+    y.backward(dy)
+    cpad = (cout + 31) // 32 * 32
+    dyg = ops.to_nhwc(dy.to(DEV), pad_to=cpad)
+    dx = ops.conv2d_dgrad(dyg, w.detach().to(DEV), (H, W), stride=stride, pad=pad)
+    assert rel_err(dx.permute(0, 3, 1, 2).cpu(), x.grad) < 2e-5
+    # accumulate flag: dx += second contribution
+    dx2 = ops.conv2d_dgrad(dyg, w.detach().to(DEV), (H, W), stride=stride, pad=pad, accumulate_into=dx.clone())
+    assert rel_err(dx2.permute(0, 3, 1, 2).cpu(), 2 * x.grad) < 2e-5
+    dw, db = ops.conv2d_wgrad(ops.to_nhwc(x.detach().to(DEV)), dyg, tuple(w.shape), stride=stride, pad=pad)
+    assert rel_err(dw.cpu(), w.grad) < 2e-5
+    assert rel_err(db.cpu(), b.grad) < 2e-5
+
+
+def test_wgrad_with_fused_input_transform():
+    from object_detection_torch2_amd import ops
+    N, H, W, cin, cout = 2, 10, 10, 128, 128
+    zprev = rnd(N, cin, H, W, seed=14)
+    scale, shift = rnd(cin, seed=15), rnd(cin, seed=16)
+    w = rnd(cout, cin, 3, 3, seed=17, scale=0.05).requires_grad_(True)
+    a = F.relu(zprev * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    y = F.conv2d(a, w, None, padding=1)
+    dy = rnd(*y.shape, seed=18)
+    y.backward(dy)
+    dw, _ = ops.conv2d_wgrad(ops.to_nhwc(zprev.to(DEV)), ops.to_nhwc(dy.to(DEV)), tuple(w.shape), pad=1,
+                             in_scale=scale.to(DEV), in_shift=shift.to(DEV), want_bias=False)
+    assert rel_err(dw.cpu(), w.grad) < 2e-5
+
+
+def test_bn_relu_backward():
+    from object_detection_torch2_amd import ops
+    N, H, W, C = 4, 10, 10, 128
+    z = rnd(N, C, H, W, seed=19).requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(rnd(C, seed=20)); bn.bias.copy_(rnd(C, seed=21) * 0.3)
+    bn.train()
+    a = F.relu(bn(z))
+    da = rnd(*a.shape, seed=22)
+    a.backward(da)
+    zg = ops.to_nhwc(z.detach().to(DEV))
+    # statistics through the same epilogue path: identity 1x1 conv would do; here compute partials directly
+    stats = torch.stack([zg.reshape(-1, C).sum(0), (zg.reshape(-1, C) ** 2).sum(0)], dim=1).reshape(1, C, 2).contiguous()
+    st = ops.bn_finalize(stats, N * H * W, bn.weight.detach().to(DEV), bn.bias.detach().to(DEV))
+    dz, dgamma, dbeta = ops.bn_relu_bwd(zg, ops.to_nhwc(da.to(DEV)), st)
+    assert rel_err(dz.permute(0, 3, 1, 2).cpu(), z.grad) < 5e-5
+    assert rel_err(dgamma.cpu(), bn.weight.grad) < 5e-5
+    assert rel_err(dbeta.cpu(), bn.bias.grad) < 5e-5
