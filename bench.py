@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of one SSD300 train step (zero_grad + forward + MultiBox loss + backward + Adam),
+batch 32 per GPU, fp32, synthetic 300x300x3 batches (BASELINE.json metric; workload = configs[2], at N>1 the weak-
+scaled data-parallel form with an RCCL gradient all-reduce).
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around the launches of the dominant kernel
+inside the timed region; `cpu_baseline` times the CPU oracle (a port of the reference path) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+GFLOP_PER_IMAGE_TRAIN = 72.238     # fwd 62.747 + wgrad 7.114 + dgrad 2.376 (VGG frozen)
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def host_cores():
+    """CPU cores this process may actually use: cgroup quota if set (the GPU box gives one GPU's share), else affinity."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, 16) if n > 64 else n      # unrestricted many-core host: use the documented 16-core share of one GPU
+
+
+def cpu_baseline(batch=8, steps=2):
+    """The oracle's train step (stock torch CPU ops + numpy loss) on this host: a bounded sample of the same workload."""
+    from oracle import ssd_oracle as O
+    from object_detection_torch2_amd import synth
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    sd = O.init_state(seed=1)
+    df = O.default_bboxes()
+    ims = torch.from_numpy(synth.images(7, batch))
+    tg = synth.targets(8, batch, g_max=8)
+    st = {}
+    O.train_step(sd, st, ims, tg, df)                 # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        O.train_step(sd, st, ims, tg, df)
+    dt = time.perf_counter() - t0
+    return dict(value=round(batch * steps / dt, 3), unit='images/sec', cores=cores, kind='port',
+                sample=f'{steps} train steps at batch {batch} (1 warm-up), torch {torch.__version__} CPU ops, {cores} threads')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    from object_detection_torch2_amd import parallel, synth
+    from object_detection_torch2_amd.model import SSD
+    from object_detection_torch2_amd.optim import FusedAdam
+    import torch.distributed as dist
+
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+
+    torch.manual_seed(1)
+    net = SSD(num_classes=21).to(dev)               # random-init weights (no pretrained weights offline)
+    df = net.default_bboxes.to(dev)
+    world_n = parallel.attach(net) if world > 1 else 1
+    opt = FusedAdam(net.train_params(), lr=1e-3, weight_decay=5e-4, grad_scale=1.0 / world_n, on_step=net.hip_weights_changed)
+    B = args.batch
+    ims = torch.from_numpy(synth.images(100 + rank, B)).to(dev)       # this rank's shard of the global batch
+    tgs = torch.from_numpy(synth.targets(200 + rank, B, g_max=8)).to(dev)
+    running = torch.zeros((), device=dev)
+
+    def step():
+        opt.zero_grad()
+        out = net(ims)
+        loss = net.loss(out, tgs, df)
+        loss.backward()
+        opt.step()
+        running.add_(loss.detach())
+
+    for _ in range(args.warmup):
+        step()
+    eng = net._engine()
+    if not args.no_roofline:
+        eng.prof = []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    final_loss = running.item() / max(1, args.steps + args.warmup)
+
+    roof = None
+    if eng.prof:
+        agg = {}
+        for r in eng.prof:
+            a = agg.setdefault(r['kernel'], dict(ms=0.0, flops=0.0, n=0, layers=set()))
+            a['ms'] += r['e0'].elapsed_time(r['e1']); a['flops'] += r['flops']; a['n'] += 1; a['layers'].add(r['layer'])
+        name, a = max(agg.items(), key=lambda kv: kv[1]['ms'])
+        ach = a['flops'] / (a['ms'] * 1e-3) / 1e12
+        roof = dict(bound='mfma', kernel=name, achieved=round(ach, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                    frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None, launches=a['n'],
+                    avg_launch_ms=round(a['ms'] / a['n'], 4), layers=sorted(a['layers']),
+                    all_conv_fwd_tflops=round(sum(v['flops'] for v in agg.values()) / (sum(v['ms'] for v in agg.values()) * 1e-3) / 1e12, 2))
+    eng.prof = None
+
+    if rank == 0:
+        value = world * B * args.steps / dt
+        line = dict(metric='images/sec SSD300 train step, batch 32/GPU', value=round(value, 2), unit='images/sec', n_gpus=world,
+                    steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
+                    scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                    config=dict(workload='SSD300 training batch=32/GPU, fp32, IoU-match thresh=0.25, hard-neg 3:1, Adam '
+                                         '(BASELINE configs[2]' + ('; data-parallel, RCCL grad all-reduce)' if world > 1 else ')'),
+                                global_batch=world * B, image='300x300x3', priors=8732, classes=21, parallelism=f'dp{world}',
+                                bn='train-mode batch statistics (reference never calls eval())', backbone='frozen VGG16-bn'),
+                    conv_flop_roofline_frac=round(value / world * GFLOP_PER_IMAGE_TRAIN / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
+                    mean_loss=round(final_loss, 4))
+        if roof is not None:
+            line['roofline'] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -76,6 +76,8 @@ typedef struct {
 int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream);
 /* m-block size the auto/explicit tile choice will use for `stats` (rows of the partial table = ceil(M/BM)) */
 int ssdhip_conv2d_block_m(const ssdhip_conv_params* p);
+/* BM*1000+BN the call will run with (profiling / bench bookkeeping) */
+int ssdhip_conv2d_tile(const ssdhip_conv_params* p);
 
 /* ---- A4  nn.BatchNorm2d, training=True (model/vgg16.py:34, model/ssd.py:62) -----------------------------
  * partial (MB,C,2) -> scale = gamma*rsqrt(var+eps), shift = beta-mean*scale (biased var); running stats EMA with

