@@ -1,0 +1,102 @@
+"""Training entry point with the reference's flags (src/train.py:15-27) on the MI355X path.
+
+    python -m object_detection_torch2_amd.train --batch_size 32 --epochs 1 [--steps_per_epoch 50]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m object_detection_torch2_amd.train ...
+
+The loop body is the reference's (train.py:103-125): zero_grad -> forward -> loss -> backward -> step, ExponentialLR per
+epoch, weights.pth / params.json when the epoch loss improves.  Differences, all deliberate: data are synthetic batches
+(the Pascal-VOC loader and torchvision augmentations are outside this path and not installed here; --synthetic is the
+only source), torch.autograd.set_detect_anomaly is off, the optimizer is the fused HIP Adam, and under torchrun each
+rank takes a contiguous shard of the global batch and gradients are all-reduced with RCCL.
+"""
+import argparse
+import json
+import time
+from pathlib import Path
+
+import torch
+
+from . import parallel, synth
+from .model import SSD
+from .optim import FusedAdam
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--purpose', type=str, default='detection')
+    parser.add_argument('--imsize', type=int, default=300)
+    parser.add_argument('--batch_size', type=int, default=4)
+    parser.add_argument('--epochs', type=int, default=1)
+    parser.add_argument('--lr', type=float, default=0.001)
+    parser.add_argument('--weight_decay', type=float, default=0.0005)
+    parser.add_argument('--gamma', type=float, default=0.95)
+    parser.add_argument('--num_workers', type=int, default=8)
+    parser.add_argument('--result_dir', type=str, default='./result')
+    parser.add_argument('--weights', type=str, default='weights.pth')
+    parser.add_argument('--params', type=str, default='params.json')
+    parser.add_argument('--synthetic', action='store_true', default=True, help='synthetic 300x300x3 batches (only data source here)')
+    parser.add_argument('--steps_per_epoch', type=int, default=20)
+    args = parser.parse_args()
+    if args.purpose != 'detection':
+        raise SystemExit('only --purpose detection is on the MI355X path (VGG16 classification pre-training is out of scope)')
+
+    rank, world, local = parallel.init_from_env()
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+    weights_path = Path(args.result_dir) / args.purpose / args.weights
+    params_path = Path(args.result_dir) / args.purpose / args.params
+
+    net = SSD(num_classes=20 + 1, weights_path=weights_path,
+              weights_path_vgg16=Path(args.result_dir) / 'classification' / args.weights)
+    net.to(device)
+    defaults = net.default_bboxes.to(device)
+
+    if params_path.exists():
+        print('Params loaded.')
+        with open(params_path, 'r') as f:
+            params = json.load(f)
+        min_loss, lr, start_epoch = params['min_loss'], params['lr'], params['last_epoch']
+    else:
+        min_loss, lr, start_epoch = None, args.lr, 0
+
+    world_n = parallel.attach(net) if world > 1 else 1
+    optimizer = FusedAdam(net.train_params(), lr=lr, weight_decay=args.weight_decay, grad_scale=1.0 / world_n,
+                          on_step=net.hip_weights_changed)
+    scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=args.gamma)
+    lo, hi = parallel.shard_batch(args.batch_size * world, rank, world)      # --batch_size is per GPU
+
+    for epoch in range(1 + start_epoch, args.epochs + start_epoch + 1):
+        running = torch.zeros((), device=device)
+        t0 = time.perf_counter()
+        for i in range(args.steps_per_epoch):
+            seed = epoch * 100003 + i
+            ims = torch.from_numpy(synth.images(seed, args.batch_size * world, args.imsize)[lo:hi]).to(device)
+            gts = torch.from_numpy(synth.targets(seed, args.batch_size * world)[lo:hi]).to(device)
+            optimizer.zero_grad()
+            outputs = net(ims)
+            loss = net.loss(outputs=outputs, targets=gts, default_bboxes=defaults)
+            loss.backward()
+            optimizer.step()
+            running += loss.detach()
+        running_loss = running.item() / args.steps_per_epoch
+        dt = time.perf_counter() - t0
+        if rank == 0:
+            print(f'[Epoch {epoch}/{args.epochs + start_epoch}] loss: {round(running_loss, 5)} lr: {scheduler.get_last_lr()[0]:.6f} '
+                  f'({args.steps_per_epoch * args.batch_size * world / dt:.1f} img/s incl. synthetic data generation)')
+            if (min_loss is None) or (running_loss < min_loss):
+                parallel.sync_bn_stats(net) if world > 1 else None
+                weights_path.parent.mkdir(parents=True, exist_ok=True)
+                torch.save(net.state_dict(), weights_path)
+                min_loss = running_loss
+                with open(params_path, 'w') as f:
+                    json.dump({'min_loss': running_loss, 'lr': scheduler.get_last_lr()[0], 'last_epoch': epoch}, f, indent=4)
+        elif world > 1 and ((min_loss is None) or (running_loss < min_loss)):
+            parallel.sync_bn_stats(net)
+            min_loss = running_loss
+        scheduler.step()
+    if rank == 0:
+        print('Finished Training')
+
+
+if __name__ == '__main__':
+    main()
