@@ -31,7 +31,7 @@ struct ConvArgs {
     float* y;
     float* stats;
     long long y_batch_stride;
-    int M, Hi, Wi, Cin, cpt, Ho, Wo, HoWo, Cout, taps, stride, lgStride, pad, KP, KT, MB, NB, accumulate;
+    int M, Hi, Wi, Cin, cpt, Ho, Wo, HoWo, Cout, taps, stride, lgStride, pad, KP, KT, MB, NB, accumulate, dense;
 };
 
 template <int KS>
@@ -40,10 +40,14 @@ __device__ __forceinline__ void tap_rs(int tap, int& r, int& s) {
     else { r = (tap * 11) >> 5; s = tap - r * 3; }   // tap/3 for tap < 16
 }
 
-template <int BM, int BN, int KS, int MODE, bool XFORM, bool SMALLC>
+// ABL: timing-only ablations (wrong results): 1 = no global loads in the K loop, 2 = no LDS writes in the K loop
+template <int BM, int BN, int KS, int MODE, bool XFORM, bool SMALLC, int ABL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_igemm_kernel(ConvArgs a) {
-    constexpr int MT = BM / 64, NT = BN / 64;     // 32x32 MFMA tiles per wave
-    constexpr int AL = BM / 32, BL = BN / 32;     // float4 loads per thread per stage
+    constexpr int WROWS = BM / 2, WCOLS = BN / 2;     // per-wave output tile (wave grid 2 x 2)
+    constexpr int MT = WROWS / 32, NT = WCOLS / 32;   // 32x32 MFMA tiles per wave
+    constexpr int AL = BM / 32, BL = BN / 32;         // float4 loads per thread per stage (2 or 4)
+    constexpr int GROUPS = 4 * MT * NT;               // groups of 4 MFMAs per K-step
+    constexpr int SLICES = 17;                        // staging slices spread over the groups (see CONV_SLICE)
     __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_ROW];
     float* As = lds;
     float* Bs = lds + 2 * BM * LDS_ROW;
@@ -62,97 +66,108 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int m0 = mt_idx * BM, n0 = nt_idx * BN;
 
     // ---- per-thread gather state: AL rows of the A tile, fixed 16-B column slot --------------------------------
+    // 32-bit BYTE offsets against uniform base pointers (global_load saddr + voffset form, no 64-bit VALU math)
     const int lrow = tid >> 3, col4 = tid & 7;
-    int a_base[4], a_h[4], a_w[4];
-    a_base[2] = a_base[3] = 0; a_h[2] = a_h[3] = a_w[2] = a_w[3] = -100000;
+    const char* xb = reinterpret_cast<const char*>(a.x);
+    const char* wb = reinterpret_cast<const char*>(a.w);
+    int a_h[4], a_w[4], a_pix[4];          // MODE 0: a_pix = pixel index of tap (0,0); MODE 1: image base pixel
+    unsigned w_off[4];
 #pragma unroll
-    for (int i = 0; i < AL; ++i) {
+    for (int i = 0; i < 4; ++i) {
         int m = m0 + lrow + 32 * i;
-        if (m < a.M) {
+        if (i < AL && m < a.M) {
             int n = m / a.HoWo;
             int rem = m - n * a.HoWo;
             int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-            a_base[i] = n * a.Hi * a.Wi;
-            if (MODE == 0) { a_h[i] = ho * a.stride - a.pad; a_w[i] = wo * a.stride - a.pad; }
-            else { a_h[i] = ho + a.pad; a_w[i] = wo + a.pad; }
+            if (MODE == 0) {
+                a_h[i] = ho * a.stride - a.pad; a_w[i] = wo * a.stride - a.pad;
+                a_pix[i] = (n * a.Hi + a_h[i]) * a.Wi + a_w[i];
+            } else {
+                a_h[i] = ho + a.pad; a_w[i] = wo + a.pad;
+                a_pix[i] = n * a.Hi * a.Wi;
+            }
         } else {
-            a_base[i] = 0; a_h[i] = -100000; a_w[i] = -100000;
+            a_h[i] = -100000; a_w[i] = -100000; a_pix[i] = 0;
         }
+        w_off[i] = (unsigned)(((n0 + lrow + 32 * (i < BL ? i : 0)) * a.KP + col4 * 4) * 4);
     }
-    const float* wrow[4];
-    wrow[2] = wrow[3] = a.w;
-#pragma unroll
-    for (int i = 0; i < BL; ++i) wrow[i] = a.w + (size_t)(n0 + lrow + 32 * i) * a.KP + col4 * 4;
 
-    // Staging registers are NAMED scalars driven by macros (no arrays, no lambdas, no conditional stages): hipcc kept
-    // array/lambda forms of this code in scratch memory.  Loads are unconditional (out-of-image taps read the tensor base
-    // and are zeroed at store time; the last iteration re-loads the final stage) so there are no branches and no early
-    // s_waitcnt: the global loads of tile kt+1 stay in flight under the MFMAs of tile kt.
+    // ---- staging state -------------------------------------------------------------------------------------------
+    // Registers are NAMED scalars driven by macros (no arrays / lambdas / conditional stages: hipcc kept those forms in
+    // scratch).  Loads are unconditional (out-of-image taps read the tensor base and are zeroed at LDS-store time; past
+    // the last K-step the final stage is re-loaded), so there are no branches and no early s_waitcnt.
     float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, sc, sh;
-    ra2 = ra3 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
-    unsigned okmask;
-    // k = tap * Cin + c.  Cin % 32 == 0: a stage is 32 channels of one tap (tap uniform over the block);
-    // SMALLC (Cin == 4, the padded RGB image): a stage is 8 taps x 4 channels, one tap per 16-B slot.
-#define CONV_LOAD_A(I)                                                                                                \
+    ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = sc = sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned okmask = 0;
+    // loader position: stage ld_kt = (tap ld_tap, channel block ld_cc); k = tap * Cin + c.
+    // Cin % 32 == 0: a stage is 32 channels of one tap (uniform); SMALLC (Cin == 4, padded RGB): 8 taps x 4 channels.
+    int ld_kt = 0, ld_tap = 0, ld_cc = 0;
+    int tap, r, s, c;
+    unsigned tapoff, woff_k;
+#define CONV_PREP()                                                                                                   \
     {                                                                                                                 \
-        int hi, wi;                                                                                                   \
-        bool ok = tap < a.taps;                                                                                       \
-        if (MODE == 0) { hi = a_h[I] + r; wi = a_w[I] + s; }                                                          \
-        else {                                                                                                        \
-            int th = a_h[I] - r, tw = a_w[I] - s;                                                                     \
-            ok = ok && ((th | tw) & (a.stride - 1)) == 0 && th >= 0 && tw >= 0;                                       \
-            hi = th >> a.lgStride; wi = tw >> a.lgStride;                                                             \
-        }                                                                                                             \
-        ok = ok && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi;                                    \
-        const int pix = ok ? (a_base[I] + hi * a.Wi + wi) : 0;                                                        \
-        ra##I = *reinterpret_cast<const float4*>(a.x + (size_t)pix * a.Cin + c);                                      \
-        okmask |= (ok ? 1u : 0u) << I;                                                                                \
-    }
-#define CONV_LOAD_STAGE(KT_)                                                                                          \
-    {                                                                                                                 \
-        const int kt_ = (KT_);                                                                                        \
-        int tap, c;                                                                                                   \
-        if (SMALLC) { tap = kt_ * 8 + col4; c = 0; }                                                                  \
-        else { tap = kt_ / a.cpt; c = (kt_ - tap * a.cpt) * BK + col4 * 4; }                                          \
-        int r, s;                                                                                                     \
+        if (SMALLC) { tap = ld_kt * 8 + col4; c = 0; }                                                                \
+        else { tap = ld_tap; c = ld_cc * BK + col4 * 4; }                                                             \
         tap_rs<KS>(tap, r, s);                                                                                        \
+        if (MODE == 0) tapoff = (unsigned)(((r * a.Wi + s) * a.Cin + c) * 4);                                         \
+        woff_k = (unsigned)(ld_kt * BK * 4);                                                                          \
         if (XFORM) {                                                                                                  \
             sc = *reinterpret_cast<const float4*>(a.in_scale + c);                                                    \
             sh = *reinterpret_cast<const float4*>(a.in_shift + c);                                                    \
         }                                                                                                             \
         okmask = 0;                                                                                                   \
-        rb0 = *reinterpret_cast<const float4*>(wrow[0] + kt_ * BK);                                                   \
-        rb1 = *reinterpret_cast<const float4*>(wrow[1] + kt_ * BK);                                                   \
-        if (BL > 2) {                                                                                                 \
-            rb2 = *reinterpret_cast<const float4*>(wrow[BL > 2 ? 2 : 0] + kt_ * BK);                                  \
-            rb3 = *reinterpret_cast<const float4*>(wrow[BL > 2 ? 3 : 0] + kt_ * BK);                                  \
+        if (ld_kt < a.KT - 1) {                                                                                       \
+            ++ld_kt;                                                                                                  \
+            if (++ld_cc == a.cpt) { ld_cc = 0; ++ld_tap; }                                                            \
         }                                                                                                             \
-        CONV_LOAD_A(0) CONV_LOAD_A(1)                                                                                 \
-        if (AL > 2) { CONV_LOAD_A(2) CONV_LOAD_A(3) }                                                                 \
     }
+#define CONV_LOAD_A(I)                                                                                                \
+    if (AL > I) {                                                                                                     \
+        bool ok = tap < a.taps;                                                                                       \
+        unsigned off;                                                                                                 \
+        if (MODE == 0) {                                                                                              \
+            ok = ok && (unsigned)(a_h[I] + r) < (unsigned)a.Hi && (unsigned)(a_w[I] + s) < (unsigned)a.Wi;            \
+            off = (unsigned)(a_pix[I] * a.Cin * 4) + tapoff;                                                          \
+        } else {                                                                                                      \
+            const int th = a_h[I] - r, tw = a_w[I] - s;                                                               \
+            const int hi = th >> a.lgStride, wi = tw >> a.lgStride;                                                   \
+            ok = ok && ((th | tw) & (a.stride - 1)) == 0 && th >= 0 && tw >= 0 && hi < a.Hi && wi < a.Wi;             \
+            off = (unsigned)(((a_pix[I] + hi * a.Wi + wi) * a.Cin + c) * 4);                                          \
+        }                                                                                                             \
+        if (ABL != 1 || !in_loop) ra##I = *reinterpret_cast<const float4*>(xb + (ok ? off : 0u));                     \
+        else ra##I.x += __uint_as_float(off & 1u);                                                                    \
+        okmask |= (ok ? 1u : 0u) << I;                                                                                \
+    }
+#define CONV_LOAD_B(I) if (BL > I) { if (ABL != 1 || !in_loop) rb##I = *reinterpret_cast<const float4*>(wb + (w_off[I] + woff_k)); else rb##I.x += __uint_as_float(woff_k & 1u); }
 #define CONV_STORE_A(I)                                                                                               \
-    {                                                                                                                 \
+    if (AL > I) {                                                                                                     \
         float4 v = ra##I;                                                                                             \
         if (XFORM) {                                                                                                  \
             v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);                         \
             v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);                         \
         }                                                                                                             \
         if (!((okmask >> I) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f); /* zero padding AFTER the transform */        \
-        *reinterpret_cast<float4*>(Ab_ + 32 * I * LDS_ROW) = v;                                                       \
+        if (ABL != 2 || !in_loop) *reinterpret_cast<float4*>(Ast_ + 32 * I * LDS_ROW) = v;                            \
+        else asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));                                              \
     }
-#define CONV_STORE_STAGE(BUF_)                                                                                        \
-    {                                                                                                                 \
-        float* Ab_ = As + (BUF_) * BM * LDS_ROW + lrow * LDS_ROW + col4 * 4;                                          \
-        float* Bb_ = Bs + (BUF_) * BN * LDS_ROW + lrow * LDS_ROW + col4 * 4;                                          \
-        *reinterpret_cast<float4*>(Bb_) = rb0;                                                                        \
-        *reinterpret_cast<float4*>(Bb_ + 32 * LDS_ROW) = rb1;                                                         \
-        if (BL > 2) {                                                                                                 \
-            *reinterpret_cast<float4*>(Bb_ + 64 * LDS_ROW) = rb2;                                                     \
-            *reinterpret_cast<float4*>(Bb_ + 96 * LDS_ROW) = rb3;                                                     \
-        }                                                                                                             \
-        CONV_STORE_A(0) CONV_STORE_A(1)                                                                               \
-        if (AL > 2) { CONV_STORE_A(2) CONV_STORE_A(3) }                                                               \
+#define CONV_STORE_B(I) if (BL > I) { if (ABL != 2 || !in_loop) *reinterpret_cast<float4*>(Bst_ + 32 * I * LDS_ROW) = rb##I; else asm volatile("" :: "v"(rb##I.x), "v"(rb##I.y), "v"(rb##I.z), "v"(rb##I.w)); }
+    // slice N of the staging work of one K-step: 0-7 write tile kt+1 (registers) to LDS, 8 advances the loader,
+    // 9-16 issue the global loads of tile kt+2 into the same registers.  N is a constant after unrolling.
+#define CONV_SLICE(N)                                                                                                 \
+    switch (N) {                                                                                                      \
+        case 0: CONV_STORE_B(0) break;  case 1: CONV_STORE_B(1) break;                                                \
+        case 2: CONV_STORE_B(2) break;  case 3: CONV_STORE_B(3) break;                                                \
+        case 4: CONV_STORE_A(0) break;  case 5: CONV_STORE_A(1) break;                                                \
+        case 6: CONV_STORE_A(2) break;  case 7: CONV_STORE_A(3) break;                                                \
+        case 8: CONV_PREP() break;                                                                                    \
+        case 9: CONV_LOAD_B(0) break;   case 10: CONV_LOAD_B(1) break;                                                \
+        case 11: CONV_LOAD_B(2) break;  case 12: CONV_LOAD_B(3) break;                                                \
+        case 13: CONV_LOAD_A(0) break;  case 14: CONV_LOAD_A(1) break;                                                \
+        case 15: CONV_LOAD_A(2) break;  case 16: CONV_LOAD_A(3) break;                                                \
+        default: break;                                                                                               \
     }
+#define CONV_LOAD_ALL() { CONV_PREP() CONV_LOAD_B(0) CONV_LOAD_B(1) CONV_LOAD_B(2) CONV_LOAD_B(3) CONV_LOAD_A(0) CONV_LOAD_A(1) CONV_LOAD_A(2) CONV_LOAD_A(3) }
+#define CONV_STORE_ALL() { CONV_STORE_B(0) CONV_STORE_B(1) CONV_STORE_B(2) CONV_STORE_B(3) CONV_STORE_A(0) CONV_STORE_A(1) CONV_STORE_A(2) CONV_STORE_A(3) }
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -162,43 +177,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    CONV_LOAD_STAGE(0)
-    CONV_STORE_STAGE(0)
+    // ---- software pipeline, two tiles ahead ------------------------------------------------------------------------
+    // LDS holds tile kt, registers hold tile kt+1 (loaded one K-step ago).  K-step kt: 16*MT*NT MFMAs on tile kt in groups
+    // of four; after each group one staging slice (registers -> LDS for tile kt+1, then the loads of tile kt+2) issues in
+    // the matrix pipe's shadow.  sched_barrier(0) pins the group/slice order; one barrier per K-step.
+    float* Ast_ = As + lrow * LDS_ROW + col4 * 4;
+    float* Bst_ = Bs + lrow * LDS_ROW + col4 * 4;
+    bool in_loop = false;
+    CONV_LOAD_ALL()          // tile 0
+    CONV_STORE_ALL()
+    CONV_LOAD_ALL()          // tile 1 (or tile 0 again when KT == 1)
     __syncthreads();
 
+    in_loop = true;
     const int frow = lane & 31, fk = (lane >> 5) * 4;
-    const int last = a.KT - 1;
+    const float* Afr = As + (wm * WROWS + frow) * LDS_ROW + fk;
+    const float* Bfr = Bs + (wn * WCOLS + frow) * LDS_ROW + fk;
     for (int kt = 0; kt < a.KT; ++kt) {
         const int buf = kt & 1;
-        CONV_LOAD_STAGE(kt < last ? kt + 1 : last)
-        __builtin_amdgcn_sched_barrier(0);   // keep every global load of tile kt+1 ahead of the MFMA block (hipcc sinks them)
-        const float* Ab = As + buf * BM * LDS_ROW + (wm * (BM / 2) + frow) * LDS_ROW + fk;
-        const float* Bb = Bs + buf * BN * LDS_ROW + (wn * (BN / 2) + frow) * LDS_ROW + fk;
+        Ast_ = As + (buf ^ 1) * BM * LDS_ROW + lrow * LDS_ROW + col4 * 4;
+        Bst_ = Bs + (buf ^ 1) * BN * LDS_ROW + lrow * LDS_ROW + col4 * 4;
+        const float* Ab = Afr + buf * BM * LDS_ROW;
+        const float* Bb = Bfr + buf * BN * LDS_ROW;
+        float4 fa[2][MT], fb[2][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[0][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_ROW);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[0][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_ROW);
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
-            float4 fa[MT], fb[NT];
+            const int cur = kc & 1;
+            if (kc < 3) {      // fragments of the next k-chunk, in flight under this chunk's MFMAs
 #pragma unroll
-            for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_ROW + kc * 8);
+                for (int i = 0; i < MT; ++i) fa[cur ^ 1][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_ROW + (kc + 1) * 8);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_ROW + kc * 8);
+                for (int j = 0; j < NT; ++j) fb[cur ^ 1][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_ROW + (kc + 1) * 8);
+            }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fb[cur][j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fb[cur][j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, fb[cur][j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].w, fb[cur][j].w, acc[i][j], 0, 0, 0);
+                    constexpr int dummy = 0; (void)dummy;
+                    const int g = (kc * MT + i) * NT + j;
+#pragma unroll
+                    for (int sl = 0; sl < SLICES; ++sl)
+                        if (sl >= g * SLICES / GROUPS && sl < (g + 1) * SLICES / GROUPS) { CONV_SLICE(sl) }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
         }
-        __builtin_amdgcn_sched_barrier(0);   // ... and the wait + LDS write of that tile behind it
-        CONV_STORE_STAGE(buf ^ 1)      // on the last iteration this fills a buffer nobody reads
         __syncthreads();
     }
-#undef CONV_LOAD_STAGE
-#undef CONV_STORE_STAGE
+#undef CONV_PREP
 #undef CONV_LOAD_A
+#undef CONV_LOAD_B
 #undef CONV_STORE_A
+#undef CONV_STORE_B
+#undef CONV_SLICE
+#undef CONV_LOAD_ALL
+#undef CONV_STORE_ALL
 
     // ---- epilogue ------------------------------------------------------------------------------------------------
     // C/D map of the 32x32 tile: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
@@ -206,7 +246,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float s1[NT], s2[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int co = n0 + wn * (BN / 2) + j * 32 + ccol;
+        const int co = n0 + wn * WCOLS + j * 32 + ccol;
         const bool cok = co < a.Cout;
         const float bv = (a.bias != nullptr && cok) ? a.bias[co] : 0.f;
         float t1 = 0.f, t2 = 0.f;
@@ -214,12 +254,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + rquad;
+                const int m = m0 + wm * WROWS + i * 32 + (e & 3) + 8 * (e >> 2) + rquad;
                 if (m < a.M && cok) {
                     float v = acc[i][j][e] + bv;
-                    const int n = m / a.HoWo;
-                    const int rem = m - n * a.HoWo;
-                    float* dst = a.y + (size_t)n * a.y_batch_stride + (size_t)rem * a.Cout + co;
+                    float* dst;
+                    if (a.dense) dst = a.y + (size_t)m * a.Cout + co;      // plain NHWC: no per-element division
+                    else {
+                        const int n = m / a.HoWo;
+                        const int rem = m - n * a.HoWo;
+                        dst = a.y + (size_t)n * a.y_batch_stride + (size_t)rem * a.Cout + co;
+                    }
                     if (a.accumulate) v += *dst;
                     *dst = v;
                     t1 += v;
@@ -231,13 +275,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     if (a.stats != nullptr) {
         __syncthreads();                       // all waves are done with the staging buffers
-        float* red = lds;                      // [wm][BN][2]
+        float* red = lds;                      // [2][BN][2]
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
             float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
             if (lane < 32) {
-                const int cl = wn * (BN / 2) + j * 32 + lane;
+                const int cl = wn * WCOLS + j * 32 + lane;
                 red[(wm * BN + cl) * 2] = t1;
                 red[(wm * BN + cl) * 2 + 1] = t2;
             }
@@ -275,13 +319,15 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 int choose_tile(const ssdhip_conv_params* p, int& BM, int& BN) {
-    if (p->tile) { BM = p->tile / 1000; BN = p->tile % 1000; }
+    if (p->tile) { BM = (p->tile / 1000) % 1000; BN = p->tile % 1000; }
     else {
         const int64_t M = (int64_t)p->N * p->Ho * p->Wo;
         BN = (p->Cout <= 64 || cdiv(p->Cout, 64) * 64 < cdiv(p->Cout, 128) * 128) ? 64 : 128;
         BM = 128;
-        // small grids: halve the m-tile so the chip (256 CUs x 2 resident blocks) sees enough tiles per round
+        // small grids: smaller tiles so the chip (256 CUs x >= 2 resident blocks) sees enough tiles per round
+        // (thresholds measured with scripts/conv_bench.py)
         if ((int64_t)cdiv(M, 128) * cdiv(p->Cout, BN) < 1024) BM = 64;
+        if (BM == 64 && BN == 128 && (int64_t)cdiv(M, 64) * cdiv(p->Cout, 128) < 1024) BN = 64;
     }
     if (!((BM == 128 || BM == 64) && (BN == 128 || BN == 64))) return SSDHIP_EINVAL;
     return SSDHIP_OK;
@@ -327,8 +373,8 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
     SSDHIP_REQUIRE(p->mode == 0 || p->mode == 1, "conv2d: mode 0 (fwd) or 1 (dgrad)");
     SSDHIP_REQUIRE(!(p->mode == 1 && p->in_scale), "conv2d: no input transform in dgrad mode");
     SSDHIP_REQUIRE((p->in_scale == nullptr) == (p->in_shift == nullptr), "conv2d: in_scale and in_shift go together");
-    SSDHIP_REQUIRE((int64_t)p->N * p->Hi * p->Wi * p->Cin < (1ll << 31) && (int64_t)p->N * p->Ho * p->Wo < (1ll << 31),
-                   "conv2d: tensor too large for 32-bit pixel indexing");
+    SSDHIP_REQUIRE((int64_t)p->N * p->Hi * p->Wi * p->Cin < (1ll << 30) && (int64_t)p->N * p->Ho * p->Wo < (1ll << 31),
+                   "conv2d: input tensor must stay below 4 GiB (32-bit byte offsets)");
     if (p->mode == 0) {
         SSDHIP_REQUIRE(p->Ho == (p->Hi + 2 * p->pad - p->R) / p->stride + 1 && p->Wo == (p->Wi + 2 * p->pad - p->S) / p->stride + 1,
                        "conv2d: output size does not match input/stride/pad");
@@ -342,8 +388,17 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
     a.Ho = p->Ho; a.Wo = p->Wo; a.HoWo = p->Ho * p->Wo; a.Cout = p->Cout; a.taps = p->R * p->S;
     a.stride = p->stride; a.lgStride = ilog2(p->stride); a.pad = p->pad; a.KP = p->KP; a.KT = p->KP / BK;
     a.MB = cdiv(a.M, BM); a.NB = cdiv(p->Cout, BN); a.accumulate = p->accumulate;
+    a.dense = p->y_batch_stride == (int64_t)p->Ho * p->Wo * p->Cout;
     hipStream_t st = (hipStream_t)stream;
     const bool xf = p->in_scale != nullptr;
+    if (p->tile >= 1000000) {   // timing-only ablations of the 128x128 3x3 kernel (scripts/conv_bench.py)
+        SSDHIP_REQUIRE(BM == 128 && BN == 128 && p->R == 3 && p->mode == 0 && p->Cin != 4 && xf, "conv2d: ablation tile");
+        dim3 grid(a.MB * a.NB), block(256);
+        if (p->tile / 1000000 == 1) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 3, 0, true, false, 1>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 3, 0, true, false, 2>), grid, block, 0, st, a);
+        SSDHIP_CHECK_LAUNCH();
+        return SSDHIP_OK;
+    }
     const int key = BM * 1000 + BN;
 #define SSDHIP_CONV_CASE(bm, bn)                                            \
     case bm * 1000 + bn:                                                    \

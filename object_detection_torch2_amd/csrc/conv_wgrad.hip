@@ -16,15 +16,31 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int TM = 128, TN = 128, TK = 32;
 
+struct FastDiv {   // exact n / d for 0 <= n < 2^31 (round-up magic number, 64-bit add): replaces ~40-instruction integer division
+    unsigned mul, shift;
+};
+static FastDiv make_fastdiv(unsigned d) {
+    FastDiv f;
+    unsigned l = 0;
+    while ((1u << l) < d) ++l;
+    f.shift = l;
+    f.mul = (unsigned)((((unsigned long long)1 << 32) * (((unsigned long long)1 << l) - d)) / d + 1);
+    return f;
+}
+__device__ __forceinline__ int fastdiv(int n, FastDiv f) {
+    return (int)(((unsigned long long)__umulhi((unsigned)n, f.mul) + (unsigned)n) >> f.shift);
+}
+
 struct WgradArgs {
     const float* x; const float* dy; const float* in_scale; const float* in_shift; float* ws;
     long long dy_batch_stride;
     int M, Hi, Wi, Cin, Ho, Wo, HoWo, Cout, CoutRow, KS, taps, stride, pad;
     int CB, IB, splitK, stages_per_split, stages, CoutT, CinT;
+    FastDiv dHoWo, dWo;
 };
 
 template <bool XFORM>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_kernel(WgradArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TK * TM];
     float* As = lds;                 // [2][TK][TM]  dy rows
     float* Bs = lds + 2 * TK * TM;   // [2][TK][TN]  gathered input rows
@@ -43,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     const int st0 = split * a.stages_per_split;
     const int st1 = min(a.stages, st0 + a.stages_per_split);
 
-    float4 sc, sh;
+    float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
     const int ci = ci0 + col4 * 4;
     const bool ci_ok = ci < a.Cin;
     if (XFORM && ci_ok) {
@@ -53,36 +69,46 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     const int co = co0 + col4 * 4;
     const bool co_ok = co < a.CoutRow;
 
-    float4 ra[4], rb[4];
-    auto load_stage = [&](int st) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = st * TK + lrow + 8 * i;
-            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-            if (m < a.M) {
-                const int n = m / a.HoWo;
-                const int rem = m - n * a.HoWo;
-                if (co_ok) va = *reinterpret_cast<const float4*>(a.dy + (size_t)n * a.dy_batch_stride + (size_t)rem * a.CoutRow + co);
-                const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-                const int hi = ho * a.stride - a.pad + r, wi = wo * a.stride - a.pad + s;
-                if (ci_ok && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi) {
-                    vb = *reinterpret_cast<const float4*>(a.x + ((size_t)(n * a.Hi + hi) * a.Wi + wi) * a.Cin + ci);
-                    if (XFORM) {
-                        vb.x = fmaxf(fmaf(vb.x, sc.x, sh.x), 0.f); vb.y = fmaxf(fmaf(vb.y, sc.y, sh.y), 0.f);
-                        vb.z = fmaxf(fmaf(vb.z, sc.z, sh.z), 0.f); vb.w = fmaxf(fmaf(vb.w, sc.w, sh.w), 0.f);
-                    }
-                }
-            }
-            ra[i] = va; rb[i] = vb;
-        }
-    };
-    auto store_stage = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<float4*>(As + (buf * TK + lrow + 8 * i) * TM + col4 * 4) = ra[i];
-            *reinterpret_cast<float4*>(Bs + (buf * TK + lrow + 8 * i) * TN + col4 * 4) = rb[i];
-        }
-    };
+    // Same staging discipline as conv_igemm.hip: named registers, unconditional loads (masked at LDS-store time),
+    // loads of tile st+1 pinned ahead of the MFMA block of tile st, store phase at raised priority.
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    unsigned amask, bmask;
+#define WG_LOAD(I)                                                                                                    \
+    {                                                                                                                 \
+        const int m = st_ * TK + lrow + 8 * I;                                                                        \
+        const bool mok = m < a.M;                                                                                     \
+        const int n = fastdiv(m, a.dHoWo);                                                                            \
+        const int rem = m - n * a.HoWo;                                                                               \
+        const int ho = fastdiv(rem, a.dWo), wo = rem - ho * a.Wo;                                                     \
+        const int hi = ho * a.stride - a.pad + r, wi = wo * a.stride - a.pad + s;                                     \
+        const bool aok = mok && co_ok;                                                                                \
+        const bool bok = mok && ci_ok && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi;              \
+        const size_t aoff = aok ? (size_t)n * a.dy_batch_stride + (size_t)rem * a.CoutRow + co : (size_t)0;           \
+        const size_t boff = bok ? ((size_t)(n * a.Hi + hi) * a.Wi + wi) * a.Cin + ci : (size_t)0;                     \
+        ra##I = *reinterpret_cast<const float4*>(a.dy + aoff);                                                        \
+        rb##I = *reinterpret_cast<const float4*>(a.x + boff);                                                         \
+        amask |= (aok ? 1u : 0u) << I;                                                                                \
+        bmask |= (bok ? 1u : 0u) << I;                                                                                \
+    }
+#define WG_LOAD_STAGE(ST_) { const int st_ = (ST_); amask = 0; bmask = 0; WG_LOAD(0) WG_LOAD(1) WG_LOAD(2) WG_LOAD(3) }
+#define WG_STORE(I)                                                                                                   \
+    {                                                                                                                 \
+        float4 va = ra##I, vb = rb##I;                                                                                \
+        if (XFORM) {                                                                                                  \
+            vb.x = fmaxf(fmaf(vb.x, sc.x, sh.x), 0.f); vb.y = fmaxf(fmaf(vb.y, sc.y, sh.y), 0.f);                     \
+            vb.z = fmaxf(fmaf(vb.z, sc.z, sh.z), 0.f); vb.w = fmaxf(fmaf(vb.w, sc.w, sh.w), 0.f);                     \
+        }                                                                                                             \
+        if (!((amask >> I) & 1u)) va = make_float4(0.f, 0.f, 0.f, 0.f);                                               \
+        if (!((bmask >> I) & 1u)) vb = make_float4(0.f, 0.f, 0.f, 0.f);                                               \
+        *reinterpret_cast<float4*>(Ap_ + 8 * I * TM) = va;                                                            \
+        *reinterpret_cast<float4*>(Bp_ + 8 * I * TN) = vb;                                                            \
+    }
+#define WG_STORE_STAGE(BUF_)                                                                                          \
+    {                                                                                                                 \
+        float* Ap_ = As + ((BUF_) * TK + lrow) * TM + col4 * 4;                                                       \
+        float* Bp_ = Bs + ((BUF_) * TK + lrow) * TN + col4 * 4;                                                       \
+        WG_STORE(0) WG_STORE(1) WG_STORE(2) WG_STORE(3)                                                               \
+    }
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -93,15 +119,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
             for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
 
     if (st0 < st1) {
-        load_stage(st0);
-        store_stage(0);
+        WG_LOAD_STAGE(st0)
+        WG_STORE_STAGE(0)
     }
     __syncthreads();
     const int fi = (lane & 31) * 2, fh = lane >> 5;
+    __builtin_amdgcn_s_setprio(1);
     for (int st = st0; st < st1; ++st) {
         const int buf = (st - st0) & 1;
-        const bool more = st + 1 < st1;
-        if (more) load_stage(st + 1);
+        WG_LOAD_STAGE(st + 1 < st1 ? st + 1 : st)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
         const float* Ab = As + (buf * TK + fh) * TM + wm * 64 + fi;
         const float* Bb = Bs + (buf * TK + fh) * TN + wn * 64 + fi;
 #pragma unroll
@@ -113,9 +141,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.x, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc[1][1], 0, 0, 0);
         }
-        if (more) store_stage(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        WG_STORE_STAGE(buf ^ 1)
         __syncthreads();
     }
+    __builtin_amdgcn_s_setprio(0);
+#undef WG_LOAD
+#undef WG_LOAD_STAGE
+#undef WG_STORE
+#undef WG_STORE_STAGE
     // slab store: ws[split][co][tap][ci]; tile (t,u) element e: co = co0+wm*64+2*row+t, ci = ci0+wn*64+2*(lane&31)+u
     float* slab = a.ws + (size_t)split * a.CoutT * a.taps * a.CinT;
     const int cj = ci0 + wn * 64 + (lane & 31) * 2;
@@ -185,6 +220,7 @@ void plan(const ssdhip_wgrad_params* p, WgradArgs& a) {
     a.Cout = p->Cout; a.CoutRow = p->dy_row; a.KS = p->S; a.taps = p->R * p->S; a.stride = p->stride; a.pad = p->pad;
     a.CB = cdiv(p->Cout, TM); a.IB = cdiv(p->Cin, TN);
     a.CoutT = a.CB * TM; a.CinT = a.IB * TN;
+    a.dHoWo = make_fastdiv((unsigned)a.HoWo); a.dWo = make_fastdiv((unsigned)a.Wo);
     a.stages = cdiv(a.M, TK);
     const int tiles = a.CB * a.IB * a.taps;
     int sk = cdiv(1024, tiles);

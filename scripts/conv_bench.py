@@ -24,15 +24,46 @@ for name, H, cin, cout, k, stride, pad, xf in L:
     sh = torch.randn(cin, device=DEV) if xf else None
     ho = (H + 2 * pad - k) // stride + 1
     fl = 2.0 * N * ho * ho * cout * cin * k * k
+    ok_tiles = []
     for tile in tiles:
         try:
-            ops.conv2d_nhwc(x, w, b, stride=stride, pad=pad, in_scale=sc, in_shift=sh, want_stats=True, tile=tile)
+            ops.conv2d_nhwc(x, w, b, stride=stride, pad=pad, in_scale=sc, in_shift=sh, want_stats=True, tile=tile); ok_tiles.append(tile)
         except Exception as e:
-            print(name, tile, 'ERR', e); continue
-        torch.cuda.synchronize()
+            print(name, tile, 'ERR', e)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    times = {t: [] for t in ok_tiles}
+    for _ in range(args.iters):            # interleaved rounds: every variant sees the same clock / cache state
+        for tile in ok_tiles:
+            e0.record(); ops.conv2d_nhwc(x, w, b, stride=stride, pad=pad, in_scale=sc, in_shift=sh, want_stats=True, tile=tile); e1.record()
+            torch.cuda.synchronize(); times[tile].append(e0.elapsed_time(e1))
+    for tile in ok_tiles:
+        ts = sorted(times[tile][1:] or times[tile]); best, med = ts[0], ts[len(ts) // 2]
+        print(f'{name:9s} tile {tile:6d} M={N*ho*ho:8d} N={cout:5d} K={cin*k*k:5d}  min {best:7.3f} ms {fl/best/1e9:6.1f} TF/s | median {med:7.3f} ms {fl/med/1e9:6.1f} TF/s', flush=True)
+
+# ---- backward of the trainable tail: wgrad (+bias) and dgrad at batch n ----
+if os.environ.get('BWD'):
+    T = [('conv_6_1', 19, 512, 1024, 3, 1, 1, False), ('conv_7_1', 19, 1024, 1024, 1, 1, 0, True), ('conv_8_1', 19, 1024, 256, 1, 1, 0, True),
+         ('conv_8_2', 19, 256, 512, 3, 2, 1, True), ('conv_9_1', 10, 512, 128, 1, 1, 0, True), ('conv_9_2', 10, 128, 256, 3, 2, 1, True),
+         ('det_4_3', 38, 512, 100, 3, 1, 1, False), ('det_7_1', 19, 1024, 150, 3, 1, 1, True), ('det_8_2', 10, 512, 150, 3, 1, 1, True)]
+    def timeit(fn):
+        fn(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         best = 1e9
         for _ in range(args.iters):
-            e0.record(); ops.conv2d_nhwc(x, w, b, stride=stride, pad=pad, in_scale=sc, in_shift=sh, want_stats=True, tile=tile); e1.record()
-            torch.cuda.synchronize(); best = min(best, e0.elapsed_time(e1))
-        print(f'{name:9s} tile {tile:6d} M={N*ho*ho:8d} N={cout:5d} K={cin*k*k:5d}  {best:8.3f} ms  {fl/best/1e9:7.1f} TF/s', flush=True)
+            e0.record(); fn(); e1.record(); torch.cuda.synchronize(); best = min(best, e0.elapsed_time(e1))
+        return best
+    for name, H, cin, cout, k, stride, pad, dg in T:
+        N = args.n
+        ho = (H + 2 * pad - k) // stride + 1
+        x = torch.randn(N, H, H, cin, device=DEV); sc = torch.rand(cin, device=DEV) + 0.5; sh = torch.randn(cin, device=DEV)
+        cpad = (cout + 31) // 32 * 32
+        dy = torch.randn(N, ho, ho, cpad, device=DEV)
+        w = torch.randn(cout, cin, k, k, device=DEV) * 0.05
+        fl = 2.0 * N * ho * ho * cout * cin * k * k
+        t = timeit(lambda: ops.conv2d_wgrad(x, dy, (cout, cin, k, k), stride=stride, pad=pad, in_scale=sc, in_shift=sh))
+        line = f'{name:9s} wgrad {t:8.3f} ms {fl/t/1e9:7.1f} TF/s'
+        if dg:
+            t = timeit(lambda: ops.conv2d_dgrad(dy, w, (H, H), stride=stride, pad=pad))
+            line += f' | dgrad {t:8.3f} ms {fl/t/1e9:7.1f} TF/s'
+        print(line, flush=True)

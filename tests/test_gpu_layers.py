@@ -26,6 +26,8 @@ CONV_CASES = [
     (2, 19, 19, 64, 128, 3, 1, 1, 128064),
     (2, 19, 19, 64, 128, 3, 1, 1, 64128),
     (2, 19, 19, 64, 128, 3, 1, 1, 64064),
+    (2, 9, 9, 32, 64, 3, 1, 1, 0),           # KT = 9: short K loop through the two-ahead pipeline
+    (2, 9, 9, 32, 64, 1, 1, 0, 0),           # KT = 1: single K-step
     (3, 21, 17, 3, 64, 3, 1, 1, 0),          # conv_1_1 style: RGB padded to 4 channels, ragged M
     (2, 19, 19, 128, 256, 1, 1, 0, 0),       # 1x1 (conv_7_1 style)
     (2, 19, 19, 64, 96, 3, 2, 1, 0),         # stride 2 (conv_8_2 style), Cout not a tile multiple
