@@ -4,9 +4,12 @@
 //   GEMM view   M = N*Ho*Wo output pixels, N = Cout, K = R*S*Cin (k = tap*Cin + ci, ci contiguous in NHWC)
 //   block tile  BM x BN x 32, 256 threads = 4 waves (2 x 2), each wave (BM/2) x (BN/2) = MT x NT MFMA tiles of 32x32
 //   staging     global -> registers (16 B per lane, whole 128-B channel rows) -> [fused BN scale/shift + ReLU of the
-//               producer layer, zero padding after it] -> LDS, rows padded to 36 floats so every ds_read_b128 of a
-//               16-lane group hits 16 distinct 4-bank slots (conflict-free); two LDS buffers, one barrier per K-step,
-//               next tile's global loads issued before the MFMAs of the current one
+//               producer layer, zero padding after it] -> LDS rows of 128 B whose 16-B chunks are XOR-swizzled with
+//               (row >> 1) & 7, so every ds_read_b128 lane group covers all 16 slots of the 256-B bank row (conflict-free,
+//               no padding: 64 KiB for 128x128, 48 KiB for 128x64 -> 3 blocks per CU); two LDS buffers, one barrier per
+//               K-step; two-ahead software pipeline: registers hold tile kt+1 while LDS holds tile kt, and the staging
+//               instructions (LDS writes of kt+1, address math + global loads of kt+2) are sliced between groups of four
+//               MFMAs so they issue in the matrix pipe's shadow
 //   MFMA feed   a lane reads 4 consecutive k of its row with one ds_read_b128 and issues 4 MFMAs from it: MFMA j of
 //               chunk c sums k = 8c+j (lanes 0-31) and 8c+4+j (lanes 32-63).  A and B use the same k permutation, and
 //               the sum over k is order-free, so no transposes are needed.  LDS read traffic: 16 B per lane per 4 MFMAs.
@@ -20,7 +23,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;
-constexpr int LDS_ROW = 36;  // floats per staged row (32 + 4 pad)
+constexpr int LDS_ROW = 32;  // floats per staged row: 128 B, no padding; 16-B chunks XOR-swizzled with (row >> 1) & 7
 
 struct ConvArgs {
     const float* x;
@@ -41,8 +44,11 @@ __device__ __forceinline__ void tap_rs(int tap, int& r, int& s) {
 }
 
 // ABL: timing-only ablations (wrong results): 1 = no global loads in the K loop, 2 = no LDS writes in the K loop
+template <int BM, int BN>
+struct ConvWaves { static constexpr int value = (BM + BN == 256) ? 2 : (BM + BN == 192) ? 3 : 4; };   // blocks per CU the LDS footprint admits
+
 template <int BM, int BN, int KS, int MODE, bool XFORM, bool SMALLC, int ABL = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWaves<BM, BN>::value))) void conv_igemm_kernel(ConvArgs a) {
     constexpr int WROWS = BM / 2, WCOLS = BN / 2;     // per-wave output tile (wave grid 2 x 2)
     constexpr int MT = WROWS / 32, NT = WCOLS / 32;   // 32x32 MFMA tiles per wave
     constexpr int AL = BM / 32, BL = BN / 32;         // float4 loads per thread per stage (2 or 4)
@@ -181,8 +187,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // LDS holds tile kt, registers hold tile kt+1 (loaded one K-step ago).  K-step kt: 16*MT*NT MFMAs on tile kt in groups
     // of four; after each group one staging slice (registers -> LDS for tile kt+1, then the loads of tile kt+2) issues in
     // the matrix pipe's shadow.  sched_barrier(0) pins the group/slice order; one barrier per K-step.
-    float* Ast_ = As + lrow * LDS_ROW + col4 * 4;
-    float* Bst_ = Bs + lrow * LDS_ROW + col4 * 4;
+    // LDS image: row r, logical 16-B chunk q lives at chunk q ^ ((r >> 1) & 7): rows r and r+32 share the swizzle, and any
+    // 16 rows of a ds_read_b128 lane group cover all 16 slots of the 256-B bank row (conflict-free without padding)
+    const int st_chunk = (col4 ^ ((lrow >> 1) & 7)) * 4;
+    float* Ast_ = As + lrow * LDS_ROW + st_chunk;
+    float* Bst_ = Bs + lrow * LDS_ROW + st_chunk;
     bool in_loop = false;
     CONV_LOAD_ALL()          // tile 0
     CONV_STORE_ALL()
@@ -190,28 +199,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __syncthreads();
 
     in_loop = true;
-    const int frow = lane & 31, fk = (lane >> 5) * 4;
-    const float* Afr = As + (wm * WROWS + frow) * LDS_ROW + fk;
-    const float* Bfr = Bs + (wn * WCOLS + frow) * LDS_ROW + fk;
+    const int frow = lane & 31, fh = lane >> 5, fx = (frow >> 1) & 7;
+    int fko[4];                      // float offset of k-chunk kc for this lane: logical chunk 2*kc + fh, swizzled
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) fko[kc] = ((2 * kc + fh) ^ fx) * 4;
+    const float* Afr = As + (wm * WROWS + frow) * LDS_ROW;
+    const float* Bfr = Bs + (wn * WCOLS + frow) * LDS_ROW;
     for (int kt = 0; kt < a.KT; ++kt) {
         const int buf = kt & 1;
-        Ast_ = As + (buf ^ 1) * BM * LDS_ROW + lrow * LDS_ROW + col4 * 4;
-        Bst_ = Bs + (buf ^ 1) * BN * LDS_ROW + lrow * LDS_ROW + col4 * 4;
+        Ast_ = As + (buf ^ 1) * BM * LDS_ROW + lrow * LDS_ROW + st_chunk;
+        Bst_ = Bs + (buf ^ 1) * BN * LDS_ROW + lrow * LDS_ROW + st_chunk;
         const float* Ab = Afr + buf * BM * LDS_ROW;
         const float* Bb = Bfr + buf * BN * LDS_ROW;
         float4 fa[2][MT], fb[2][NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) fa[0][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_ROW);
+        for (int i = 0; i < MT; ++i) fa[0][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_ROW + fko[0]);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) fb[0][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_ROW);
+        for (int j = 0; j < NT; ++j) fb[0][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_ROW + fko[0]);
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
             const int cur = kc & 1;
             if (kc < 3) {      // fragments of the next k-chunk, in flight under this chunk's MFMAs
 #pragma unroll
-                for (int i = 0; i < MT; ++i) fa[cur ^ 1][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_ROW + (kc + 1) * 8);
+                for (int i = 0; i < MT; ++i) fa[cur ^ 1][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_ROW + fko[kc < 3 ? kc + 1 : 0]);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) fb[cur ^ 1][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_ROW + (kc + 1) * 8);
+                for (int j = 0; j < NT; ++j) fb[cur ^ 1][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_ROW + fko[kc < 3 ? kc + 1 : 0]);
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -327,7 +339,7 @@ int choose_tile(const ssdhip_conv_params* p, int& BM, int& BN) {
         // small grids: smaller tiles so the chip (256 CUs x >= 2 resident blocks) sees enough tiles per round
         // (thresholds measured with scripts/conv_bench.py)
         if ((int64_t)cdiv(M, 128) * cdiv(p->Cout, BN) < 1024) BM = 64;
-        if (BM == 64 && BN == 128 && (int64_t)cdiv(M, 64) * cdiv(p->Cout, 128) < 1024) BN = 64;
+        if (BM == 64 && BN == 128 && (int64_t)cdiv(M, 64) * cdiv(p->Cout, 128) < 512) BN = 64;
     }
     if (!((BM == 128 || BM == 64) && (BN == 128 || BN == 64))) return SSDHIP_EINVAL;
     return SSDHIP_OK;

@@ -300,7 +300,9 @@ class Engine:
         p.in_scale = xs[0].data_ptr() if xs is not None else None
         p.in_shift = xs[1].data_ptr() if xs is not None else None
         p.dw_oihw = views[prefix + '.weight'].data_ptr()
-        p.dbias = views[prefix + '.bias'].data_ptr() if (prefix + '.bias') in views else None
+        # conv bias in front of a train-mode BatchNorm: d bias = sum(dz) = 0 exactly (BN removes the batch mean), the
+        # reference's autograd holds rounding noise there; the flat buffer slot stays 0 (zeroed at allocation)
+        p.dbias = views[prefix + '.bias'].data_ptr() if (spec.is_head and (prefix + '.bias') in views) else None
         p.ws = bw['wgrad_ws'].data_ptr()
         _lib.check(self.lib.ssdhip_conv2d_wgrad(ctypes.byref(p), _lib.stream()), f'wgrad {spec.name}')
 
@@ -368,9 +370,15 @@ class Engine:
                                                   _lib.ptr(bst['mean']), _lib.ptr(bst['invstd']), _lib.ptr(bw['coef']), M, c.cout,
                                                   _lib.ptr(dz), st), 'bn_relu_bwd_apply')
             xin, xin_xs = acts[i - 1][2], acts[i - 1][3]
+            if i == self.tail_start and self.dist_hook is not None:
+                # every gradient behind the first stage's parameters is final: reduce it while the largest wgrad runs
+                first = f'features.{c.name}.weight'
+                cut = self._flat['offs'][names.index(f'features.{self.stages[i + 1].conv.name}.weight')]
+                assert self._flat['offs'][names.index(first)] == 0
+                self.dist_hook.start(flat, cut, flat.numel())
             self._wgrad(c, xin, xin_xs, dz, views, bw, N, g['hi'], g['wi'], g['ho'], g['wo'])
             if i > self.tail_start:
                 self._dgrad(c, dz, bw['da'][i - 1], N, g['ho'], g['wo'], g['hi'], g['wi'], accumulate=False)
         if self.dist_hook is not None:
-            self.dist_hook(flat)
+            self.dist_hook.finish(flat)
         return [views[n] for n in names], params

@@ -40,27 +40,48 @@ def shard_batch(global_batch, rank, world):
 
 
 class GradAllReduce:
-    """Engine.dist_hook: sums the flat gradient buffer over ranks in `n_buckets` contiguous all-reduce calls.
+    """Engine.dist_hook: sums the flat gradient buffer over ranks with a few large all-reduce calls, overlapped with the
+    end of backward: `start(flat, lo, hi)` is called as soon as flat[lo:hi] is final (everything except the first tail
+    stage, whose wgrad is the largest and runs last); `finish(flat)` reduces the rest and waits.  torch's NCCL(RCCL)
+    process group orders each collective after the kernels already enqueued on the current stream and runs it on its own
+    stream, so the early buckets travel over xGMI while the last wgrad kernels compute.
     The 1/world factor is applied by the optimizer (FusedAdam grad_scale) so no extra pass over the buffer is needed;
     with average=True the buffer itself is scaled (stock torch.optim users)."""
 
     def __init__(self, group=None, n_buckets=2, average=False):
         self.group, self.n_buckets, self.average = group, max(1, n_buckets), average
+        self._works, self._done_from = [], None
 
-    def bucket_ranges(self, n):
-        step = -(-n // self.n_buckets)
-        step = -(-step // 4) * 4
-        return [(lo, min(n, lo + step)) for lo in range(0, n, step)]
+    def bucket_ranges(self, n, lo=0):
+        step = -(-(n - lo) // self.n_buckets)
+        step = max(4, -(-step // 4) * 4)
+        return [(a, min(n, a + step)) for a in range(lo, n, step)]
 
-    def __call__(self, flat):
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+    def _active(self):
+        return dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def start(self, flat, lo, hi):
+        if not self._active():
             return
-        works = [dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                 for lo, hi in self.bucket_ranges(flat.numel())]
-        for w in works:
+        assert hi == flat.numel() and lo % 4 == 0
+        self._done_from = lo
+        for a, b in self.bucket_ranges(hi, lo):
+            self._works.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self, flat):
+        if not self._active():
+            return
+        end = flat.numel() if self._done_from is None else self._done_from
+        if end > 0:
+            self._works.append(dist.all_reduce(flat[:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for w in self._works:
             w.wait()
+        self._works, self._done_from = [], None
         if self.average:
             flat.mul_(1.0 / dist.get_world_size(self.group))
+
+    def __call__(self, flat):
+        self.finish(flat)
 
 
 def attach(net, n_buckets=2, average=False, group=None):

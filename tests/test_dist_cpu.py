@@ -30,7 +30,9 @@ def _worker(rank, world, port, q):
     g = torch.arange(n, dtype=torch.float32) * (rank + 1)
     hook = parallel.GradAllReduce(n_buckets=3)
     ranges = hook.bucket_ranges(n)
-    hook(g)
+    cut = 40000                      # gradients behind `cut` are final first (overlap with the last wgrad), then the head
+    hook.start(g, cut, n)
+    hook.finish(g)
     expect = torch.arange(n, dtype=torch.float32) * sum(range(1, world + 1))
     ok_sum = torch.equal(g, expect)
     g2 = torch.ones(1000) * (rank + 1)
