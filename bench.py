@@ -124,8 +124,15 @@ def main():
             a['ms'] += r['e0'].elapsed_time(r['e1']); a['flops'] += r['flops']; a['n'] += 1; a['layers'].add(r['layer'])
         name, a = max(agg.items(), key=lambda kv: kv[1]['ms'])
         ach = a['flops'] / (a['ms'] * 1e-3) / 1e12
+        traffic = None       # HBM-side bytes per launch from the committed PMC passes (scripts/collect_pmc.sh + pmc_summary.py)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')))
+            traffic = round(pmc[name]['hbm_bytes_per_launch'])
+        except (OSError, KeyError, ValueError):
+            pass
         roof = dict(bound='mfma', kernel=name, achieved=round(ach, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-                    frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None, launches=a['n'],
+                    frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic, launches=a['n'],
+                    algorithmic_flop_per_launch=round(a['flops'] / a['n']),
                     avg_launch_ms=round(a['ms'] / a['n'], 4), layers=sorted(a['layers']),
                     all_conv_fwd_tflops=round(sum(v['flops'] for v in agg.values()) / (sum(v['ms'] for v in agg.values()) * 1e-3) / 1e12, 2))
     eng.prof = None

@@ -45,8 +45,9 @@ int ssdhip_default_boxes(float* out, const int32_t* maps_host, int n_maps, doubl
 int ssdhip_normalize_nchw_to_nhwc4(const float* x, float* y, int N, int H, int W, void* stream);
 
 /* ---- weights: OIHW state_dict tensor -> packed implicit-GEMM operand ------------------------------------
- * mode 0 (fwd):   packed[co][ (r*S+s)*CinP + ci ]      rows co < CoutP (zero-filled beyond Cout/Cin/taps), row length KP
- * mode 1 (dgrad): packed[ci][ (r*S+s)*CoutP + co ]     rows ci < CinRowsP, row length KP
+ * mode 0 (fwd):   packed[co][k], k = ((ci/32)*R*S + r*S+s)*32 + ci%32  (k = (r*S+s)*4 + ci for the 4-channel padded image);
+ *                 rows co < rows_pad, zero-filled beyond Cout / Cin / taps, row length KP
+ * mode 1 (dgrad): packed[ci][k], k = ((co/32)*R*S + r*S+s)*32 + co%32, rows ci < rows_pad, row length KP
  * (model/ssd.py:61,70-77 nn.Conv2d weights; repacked after each optimizer step for trainable layers)     */
 int ssdhip_pack_conv_weight(const float* w_oihw, float* packed, int Cout, int Cin, int R, int S,
                             int rows_pad, int inner_pad, int KP, int mode, void* stream);

@@ -1,7 +1,8 @@
 // NHWC implicit-GEMM convolution on the exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32), gfx950.
 // Replaces nn.Conv2d forward (model/vgg16.py:33, model/ssd.py:61,70-77) and, in gather mode 1, its data gradient.
 //
-//   GEMM view   M = N*Ho*Wo output pixels, N = Cout, K = R*S*Cin (k = tap*Cin + ci, ci contiguous in NHWC)
+//   GEMM view   M = N*Ho*Wo output pixels, N = Cout, K = R*S*Cin walked as (32-channel block, tap, channel): ci contiguous in
+//               NHWC, and the taps of one channel block adjacent in time (cache reuse of the input lines)
 //   block tile  BM x BN x 32, 256 threads = 4 waves (2 x 2), each wave (BM/2) x (BN/2) = MT x NT MFMA tiles of 32x32
 //   staging     global -> registers (16 B per lane, whole 128-B channel rows) -> [fused BN scale/shift + ReLU of the
 //               producer layer, zero padding after it] -> LDS rows of 128 B whose 16-B chunks are XOR-swizzled with
@@ -105,8 +106,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWave
     float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, sc, sh;
     ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = sc = sh = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned okmask = 0;
-    // loader position: stage ld_kt = (tap ld_tap, channel block ld_cc); k = tap * Cin + c.
-    // Cin % 32 == 0: a stage is 32 channels of one tap (uniform); SMALLC (Cin == 4, padded RGB): 8 taps x 4 channels.
+    // loader position: stage ld_kt = (channel block ld_cc, tap ld_tap), k = (cc * taps + tap) * 32 + c % 32: channel block
+    // OUTER, tap INNER, so the 9 taps re-read each 128-B input line in 9 consecutive K-steps (L1/L2 hits; with the tap outer
+    // the re-reads were a whole K loop apart and the per-XCD L2 thrashed: 3.3x the algorithmic bytes at the fabric counters).
+    // SMALLC (Cin == 4, padded RGB): a stage is 8 taps x 4 channels, k = tap * 4 + c.
     int ld_kt = 0, ld_tap = 0, ld_cc = 0;
     int tap, r, s, c;
     unsigned tapoff, woff_k;
@@ -122,9 +125,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWave
             sh = *reinterpret_cast<const float4*>(a.in_shift + c);                                                    \
         }                                                                                                             \
         okmask = 0;                                                                                                   \
-        if (ld_kt < a.KT - 1) {                                                                                       \
+        if (ld_kt < a.KT - 1) {    /* channel block outer, tap inner: the 9 taps of one 128-B line are consecutive */ \
             ++ld_kt;                                                                                                  \
-            if (++ld_cc == a.cpt) { ld_cc = 0; ++ld_tap; }                                                            \
+            if (++ld_tap == a.taps) { ld_tap = 0; ++ld_cc; }                                                          \
         }                                                                                                             \
     }
 #define CONV_LOAD_A(I)                                                                                                \
@@ -311,13 +314,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWave
     }
 }
 
-// OIHW -> packed rows.  mode 0: row = co, inner = ci;  mode 1: row = ci, inner = co.  k = tap * inner_pad + inner.
+// OIHW -> packed rows.  mode 0: row = co, inner = ci;  mode 1: row = ci, inner = co.  k order as the loader walks it.
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cout, int Cin, int R, int S,
                                    int rows_pad, int inner_pad, int KP, int mode) {
     const int64_t total = (int64_t)rows_pad * KP;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int row = (int)(i / KP), k = (int)(i - (int64_t)row * KP);
-        const int tap = k / inner_pad, inner = k - tap * inner_pad;
+        int tap, inner;
+        if (inner_pad < 32) { tap = k / inner_pad; inner = k - tap * inner_pad; }          // padded RGB: k = tap * 4 + c
+        else {                                                                              // k = (cblk * taps + tap) * 32 + c % 32
+            const int taps = R * S, cb = k / (taps * 32), rem = k - cb * taps * 32;
+            tap = rem >> 5; inner = cb * 32 + (rem & 31);
+            if (inner >= inner_pad) tap = taps;                                             // K padding beyond the last block
+        }
         float v = 0.f;
         if (tap < R * S) {
             const int r = tap / S, s = tap - r * S;

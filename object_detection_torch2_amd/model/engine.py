@@ -176,8 +176,11 @@ class Engine:
         e0.record()
         _lib.check(self.lib.ssdhip_conv2d_nhwc(ctypes.byref(p), _lib.stream()), f'conv2d {spec.name}')
         e1.record()
-        kernel = 'conv_igemm<%d,k%d,%s>' % (self.lib.ssdhip_conv2d_tile(ctypes.byref(p)), spec.k,
-                                             'rgb' if spec.cin_pad == 4 else ('bnrelu_in' if xs is not None else 'plain_in'))
+        tile = self.lib.ssdhip_conv2d_tile(ctypes.byref(p))
+        # the symbol rocprofv3 reports for this launch (template arguments BM, BN, KS, MODE, XFORM, SMALLC, ABL)
+        kernel = 'conv_igemm_kernel<%d, %d, %d, 0, %s, %s, 0>' % (tile // 1000, tile % 1000, spec.k,
+                                                                  'true' if xs is not None else 'false',
+                                                                  'true' if spec.cin_pad == 4 else 'false')
         self.prof.append(dict(layer=spec.name, kernel=kernel, flops=2.0 * N * ho * wo * spec.cout * spec.cin * spec.k * spec.k,
                               e0=e0, e1=e1))
         return bm
