@@ -64,6 +64,8 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--mode', choices=['train', 'infer'], default='train',
+                    help='train (headline, BASELINE configs[2]) or infer (configs[1]: forward + decode + score + NMS)')
     args = ap.parse_args()
 
     from object_detection_torch2_amd import parallel, synth
@@ -87,7 +89,21 @@ def main():
     tgs = torch.from_numpy(synth.targets(200 + rank, B, g_max=8)).to(dev)
     running = torch.zeros((), device=dev)
 
+    from object_detection_torch2_amd import utils as hip_utils
+    void_bias = torch.zeros(1, 1, 25, device=dev)
+    void_bias[0, 0, 4] = 3.0           # void-biased logits, ~1.3k NMS candidates per image (trained-net regime)
+
+    def infer_step():
+        with torch.no_grad():
+            out = net(ims)
+            out += void_bias
+            hip_utils.decode_score_(out, df)
+            hip_utils.non_maximum_suppression(out)
+        running.add_(out[0, 0, 0])
+
     def step():
+        if args.mode == 'infer':
+            return infer_step()
         opt.zero_grad()
         out = net(ims)
         loss = net.loss(out, tgs, df)
@@ -139,18 +155,23 @@ def main():
 
     if rank == 0:
         value = world * B * args.steps / dt
-        line = dict(metric='images/sec SSD300 train step, batch 32/GPU', value=round(value, 2), unit='images/sec', n_gpus=world,
+        metric = 'images/sec SSD300 train step, batch 32/GPU' if args.mode == 'train' else \
+            'images/sec SSD300 inference (forward + decode + score + NMS), batch 32/GPU'
+        line = dict(metric=metric, value=round(value, 2), unit='images/sec', n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
                     scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
                     config=dict(workload='SSD300 training batch=32/GPU, fp32, IoU-match thresh=0.25, hard-neg 3:1, Adam '
                                          '(BASELINE configs[2]' + ('; data-parallel, RCCL grad all-reduce)' if world > 1 else ')'),
                                 global_batch=world * B, image='300x300x3', priors=8732, classes=21, parallelism=f'dp{world}',
                                 bn='train-mode batch statistics (reference never calls eval())', backbone='frozen VGG16-bn'),
-                    conv_flop_roofline_frac=round(value / world * GFLOP_PER_IMAGE_TRAIN / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
+                    conv_flop_roofline_frac=round(value / world * (GFLOP_PER_IMAGE_TRAIN if args.mode == 'train' else 62.747)
+                                                  / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
                     mean_loss=round(final_loss, 4))
         if roof is not None:
             line['roofline'] = roof
-        if world == 1 and not args.no_cpu_baseline:
+        if args.mode == 'infer':
+            line['config']['workload'] = 'SSD300 inference batch=32, fp32, NMS on 8732 priors x 20 classes (BASELINE configs[1])'
+        if world == 1 and not args.no_cpu_baseline and args.mode == 'train':
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -1,0 +1,148 @@
+"""Evaluation entry point with the reference's flags (src/evaluate.py:75-81): forward -> decode -> score -> NMS ->
+IoU vs GT (evaluate.py:128-132, all on the HIP path) -> per-class greedy TP assignment (evaluate.py:134-151) -> AP.
+
+`calc_average_precision(..., reference_compatible=True)` reproduces the reference's AP exactly, including its quirk:
+`torch.sort(result, dim=0)` sorts the TP column and the score column independently (evaluate.py:55), i.e. true positives
+are ranked first regardless of score (README's mAP 0.314 is this number).  reference_compatible=False
+ranks detections by score (standard VOC AP, all-point interpolation).  Data are synthetic batches (no VOC data here);
+the runtime block of the report comes from rocm-smi instead of nvidia-smi (evaluate.py:164).
+"""
+import argparse
+from datetime import date
+from pathlib import Path
+from subprocess import check_output
+
+import torch
+
+from . import synth
+from .model import SSD
+from .utils import LabelMap, calc_iou, decode_score_, non_maximum_suppression
+
+OUTPUT_FORMAT = '''
+# EVALUATION REPORT
+
+## REPORTING DATE
+{date}
+
+## RUNTIME
+```
+{runtime}
+```
+
+## CONFIG
+{config_table}
+
+## SCORES
+{score_table}
+'''
+
+
+def get_order(t: torch.Tensor, class_id: int) -> torch.Tensor:
+    """evaluate.py:31-42: indices of rows with a positive score for class_id, by descending score."""
+    vals, indices = torch.sort(t[:, 5 + class_id], descending=True)
+    return indices[vals > 0.]
+
+
+def assign_true_positives(iou_one_class: torch.Tensor) -> torch.Tensor:
+    """evaluate.py:146-148: each prediction (rows, score order) claims its best-IoU GT if IoU > 0.5; only the first
+    claimant of a GT is a true positive.  (X, G) -> (X, 1) of {0., 1.}."""
+    g = iou_one_class.shape[1]
+    best = iou_one_class.max(dim=1).indices
+    valid = torch.eye(g, device=iou_one_class.device)[best] * (iou_one_class > 0.5)
+    return ((valid.cumsum(dim=0) == valid) * valid).sum(dim=1, keepdim=True)
+
+
+def calc_average_precision(result: torch.Tensor, count, reference_compatible: bool = True) -> torch.Tensor:
+    """evaluate.py:45-67.  result (X, 2) = [is_tp, score]; count = number of GT boxes of the class."""
+    result = result.detach().cpu().float()
+    if reference_compatible:
+        correct = torch.sort(result, dim=0, descending=True).values[:, 0]       # columns sorted independently (Q11)
+    else:
+        correct = result[torch.argsort(result[:, 1], descending=True, stable=True), 0]
+    tp = torch.cumsum(correct == 1., dim=0)
+    fp = torch.cumsum(correct == 0., dim=0)
+    precision = 1.0 * tp / (tp + fp)
+    recall = 1.0 * tp / count
+    mod_precision = torch.cat([torch.Tensor([0.]), precision, torch.Tensor([0.])])
+    mod_precision = torch.flip(torch.cummax(torch.flip(mod_precision, dims=[0]), dim=0).values, dims=[0])
+    mod_recall = torch.cat([torch.Tensor([0.]), recall, torch.Tensor([1.])])
+    return torch.sum(mod_precision[1:] * (mod_recall[1:] - mod_recall[:-1]))
+
+
+def evaluate_batches(net, defaults, batches, num_classes=20):
+    """Accumulate per-class [is_tp, score] rows and GT counts over (images, gts) device batches."""
+    result_correct = {c: [] for c in range(num_classes)}
+    result_count = {c: 0 for c in range(num_classes)}
+    with torch.no_grad():
+        for images, gts in batches:
+            outputs = net(images)
+            decode_score_(outputs, defaults)
+            outputs = non_maximum_suppression(outputs=outputs)
+            ious = calc_iou(outputs, gts)
+            for output, gt, iou in zip(outputs, gts, ious):
+                for c in range(num_classes):
+                    pr_order, gt_order = get_order(output, c), get_order(gt, c)
+                    if len(pr_order) == 0:
+                        result_count[c] += len(gt_order)
+                        continue
+                    if len(gt_order) == 0:
+                        correct = torch.zeros(len(pr_order), 1, device=output.device)
+                    else:
+                        correct = assign_true_positives(iou[pr_order][:, gt_order])
+                    result_correct[c].append(torch.cat([correct, output[pr_order][:, [5 + c]]], dim=1))
+                    result_count[c] += len(gt_order)
+    return result_correct, result_count
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--imsize', type=int, default=300)
+    parser.add_argument('--batch_size', type=int, default=2)
+    parser.add_argument('--num_workers', type=int, default=8)
+    parser.add_argument('--result_dir', type=str, default='./result')
+    parser.add_argument('--weights', type=str, default='weights.pth')
+    parser.add_argument('--batches', type=int, default=2)
+    args = parser.parse_args()
+
+    out_dir = Path(args.result_dir) / 'detection'
+    out_dir.mkdir(parents=True, exist_ok=True)
+    device = torch.device('cuda:0')
+    net = SSD(num_classes=20 + 1, weights_path=out_dir / args.weights,
+              weights_path_vgg16=Path(args.result_dir) / 'classification' / args.weights)
+    net.to(device)
+    defaults = net.default_bboxes.to(device)
+    labelmap = LabelMap('PascalVOC')
+
+    def batches():
+        for b in range(args.batches):
+            yield (torch.from_numpy(synth.images(3000 + b, args.batch_size, args.imsize)).to(device),
+                   torch.from_numpy(synth.targets(4000 + b, args.batch_size)).to(device))
+
+    correct, count = evaluate_batches(net, defaults, batches())
+    score_table = ['|label|average precision (reference)|average precision (score-ranked)|', '|-|-|-|']
+    aps = []
+    for c in range(20):
+        if correct[c] and count[c] > 0:
+            rows = torch.cat(correct[c]).cpu()
+            ap_ref = calc_average_precision(rows, count[c], True).item()
+            ap_voc = calc_average_precision(rows, count[c], False).item()
+        else:
+            ap_ref = ap_voc = 0.0
+        aps.append((ap_ref, ap_voc))
+        score_table.append(f'|{labelmap.id2name(c)}|{round(ap_ref, 3)}|{round(ap_voc, 3)}|')
+    score_table.append(f'|**mean**|**{round(sum(a for a, _ in aps) / 20, 3)}**|**{round(sum(b for _, b in aps) / 20, 3)}**|')
+    try:
+        runtime = check_output(['rocm-smi', '--showproductname', '--showmeminfo', 'vram']).decode()
+    except (OSError, Exception) as e:   # noqa: BLE001
+        runtime = f'rocm-smi unavailable: {e}'
+    config_table = ['|item|value|', '|-|-|'] + [f'|{k}|{v}|' for k, v in args.__dict__.items()]
+    d = date.today().isoformat()
+    report = OUTPUT_FORMAT.format(date=d, runtime=runtime, config_table='\n'.join(config_table), score_table='\n'.join(score_table))
+    with open(out_dir / f'report_{d}.md', 'w') as f:
+        f.write(report)
+    print('\n'.join(score_table[-1:]))
+    print('Finished Evaluate')
+
+
+if __name__ == '__main__':
+    main()

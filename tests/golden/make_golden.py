@@ -275,8 +275,38 @@ def gen_forward_train():
     print('G9 train trajectory ok')
 
 
+def gen_eval():
+    """G10: the reference's AP bookkeeping (evaluate.py:31-67).  evaluate.py imports `augmentation` (needs torchvision,
+    absent here) at module level; a stub module with the two names it imports is enough to reach the two pure functions."""
+    import types
+    stub = types.ModuleType('augmentation'); stub.Compose = object; stub.ToTensor = object
+    sys.modules['augmentation'] = stub
+    import evaluate as ref_eval  # noqa: E402  (reference)
+    from object_detection_torch2_amd import evaluate as my_eval
+    fx = {}
+    rng = synth.uniform(77, 5, 4000)
+    k = 0
+    for case, n in enumerate((1, 7, 40, 200)):
+        tp = (rng[k:k + n] > 0.6).astype(np.float32); k += n
+        sc = rng[k:k + n].astype(np.float32); k += n
+        res = torch.from_numpy(np.stack([tp, sc], 1))
+        cnt = int(tp.sum()) + case + 1
+        ap = ref_eval.calc_average_precision(result=res.clone(), count=cnt)
+        assert abs(ap.item() - my_eval.calc_average_precision(res.clone(), cnt, True).item()) < 1e-7
+        fx[f'ap_ref_{case}'] = np.float32(ap.item()); fx[f'ap_cnt_{case}'] = np.int64(cnt)
+        fx[f'ap_voc_{case}'] = np.float32(my_eval.calc_average_precision(res.clone(), cnt, False).item())
+    t = torch.from_numpy(synth.uniform(78, 6, 50 * 25).astype(np.float32).reshape(50, 25)); t[::3, 5 + 4] = 0
+    o = ref_eval.get_order(t, 4)
+    assert torch.equal(o, my_eval.get_order(t, 4))
+    fx['order_c4'] = o.numpy()
+    np.savez_compressed(OUT / 'g10_eval.npz', **fx)
+    print('G10 evaluation fixtures ok')
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['post', 'fwd']
+    which = sys.argv[1:] or ['post', 'fwd', 'eval']
+    if 'eval' in which:
+        gen_eval()
     if 'post' in which:
         gen_boxes_loss_post()
     if 'fwd' in which:

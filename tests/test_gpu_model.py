@@ -133,3 +133,39 @@ def test_stock_torch_adam_also_works(env):
         opt.step()
         assert prev is None or loss.item() < prev
         prev = loss.item()
+
+
+def test_inference_and_evaluation_path(env):
+    """inference.py:65-69 / evaluate.py:128-151 on the GPU: forward -> decode -> score -> NMS -> IoU vs GT -> TP rows,
+    checked against the oracle's post-process applied to the same network outputs."""
+    from object_detection_torch2_amd import evaluate as E, utils
+    O, synth = env['O'], env['synth']
+    net = make_net(env)
+    df = net.default_bboxes.to(DEV)
+    ims = torch.from_numpy(synth.images(60, 2)).to(DEV)
+    gts = torch.from_numpy(synth.targets(61, 2, g_max=4)).to(DEV)
+    with torch.no_grad():
+        raw = net(ims)
+    raw_np = raw.cpu().numpy()
+    out = raw.clone()
+    utils.decode_score_(out, df)
+    out = utils.non_maximum_suppression(outputs=out)
+    # oracle post-process of the SAME raw outputs
+    pre = np.concatenate([O.calc_coordicate(raw_np, O.default_bboxes()), O.calc_score(raw_np)], axis=2)
+    ref = O.non_maximum_suppression(pre.copy())
+    got = out.cpu().numpy()
+    assert np.allclose(got[:, :, :4], ref[:, :, :4], rtol=2e-6, atol=1e-6)      # expf vs numpy exp: last-ulp differences
+    kept_g, kept_r = got[:, :, 5:].max(axis=2) > 0, ref[:, :, 5:].max(axis=2) > 0
+    # an untrained net yields ~6.8k candidates per image; a last-ulp box difference can flip a borderline IoU > 0.5 and the
+    # greedy chain propagates it locally, so the keep sets are compared as sets (the exact-input test is in
+    # test_gpu_boxes_loss_post.py: identical boxes -> identical keep set)
+    assert (kept_g != kept_r).sum() <= 0.005 * kept_r.sum(), ((kept_g != kept_r).sum(), kept_r.sum())
+    iou = utils.calc_iou(out, gts)
+    assert iou.shape == (2, 8732, 4)
+    correct, count = E.evaluate_batches(net, df, [(ims, gts)])
+    assert sum(count.values()) == int((gts[:, :, 2] > 0).sum())
+    for c, rows in correct.items():
+        for r in rows:
+            assert r.shape[1] == 2 and set(r[:, 0].unique().tolist()) <= {0.0, 1.0}
+            ap = E.calc_average_precision(r, max(count[c], 1), True).item()
+            assert 0.0 <= ap <= 1.0 + 1e-6

@@ -77,3 +77,26 @@ def test_synth_streams_are_reproducible():
     assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
     # pinned words: the streams must never change silently (fixtures depend on them)
     assert synth.hash_u32(1, 2, 3).tolist() == synth.hash_u32(1, 2, 3).tolist()
+
+
+def test_average_precision_matches_reference_and_voc(golden):
+    """AP bookkeeping (evaluate.py:31-67): reference-compatible mode reproduces the reference incl. its independent-column
+    sort (Q11: TPs ranked first); score-ranked mode is standard VOC AP and is never larger."""
+    from object_detection_torch2_amd import evaluate as E
+    fx = golden('g10_eval.npz')
+    rng = synth.uniform(77, 5, 4000)
+    k = 0
+    for case, n in enumerate((1, 7, 40, 200)):
+        tp = (rng[k:k + n] > 0.6).astype(np.float32); k += n
+        sc = rng[k:k + n].astype(np.float32); k += n
+        res = torch.from_numpy(np.stack([tp, sc], 1))
+        cnt = int(fx[f'ap_cnt_{case}'])
+        ref = E.calc_average_precision(res.clone(), cnt, True).item()
+        voc = E.calc_average_precision(res.clone(), cnt, False).item()
+        assert abs(ref - float(fx[f'ap_ref_{case}'])) < 1e-7 and abs(voc - float(fx[f'ap_voc_{case}'])) < 1e-7
+        assert voc <= ref + 1e-7
+    t = torch.from_numpy(synth.uniform(78, 6, 50 * 25).astype(np.float32).reshape(50, 25)); t[::3, 5 + 4] = 0
+    assert np.array_equal(E.get_order(t, 4).numpy(), fx['order_c4'])
+    # TP assignment: two predictions claim GT 0, only the first (higher score) is a TP; the third matches nothing
+    iou = torch.tensor([[0.9, 0.1], [0.8, 0.2], [0.3, 0.4]])
+    assert E.assign_true_positives(iou).view(-1).tolist() == [1.0, 0.0, 0.0]
