@@ -118,35 +118,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
 
+    // two-ahead software pipeline (same scheme as conv_igemm.hip): LDS holds tile st, registers hold tile st+1; the LDS
+    // writes of st+1 and the address math + global loads of st+2 are sliced between the 16 groups of four MFMAs.
     if (st0 < st1) {
         WG_LOAD_STAGE(st0)
         WG_STORE_STAGE(0)
+        WG_LOAD_STAGE(st0 + 1 < st1 ? st0 + 1 : st0)
     }
     __syncthreads();
     const int fi = (lane & 31) * 2, fh = lane >> 5;
-    __builtin_amdgcn_s_setprio(1);
     for (int st = st0; st < st1; ++st) {
         const int buf = (st - st0) & 1;
-        WG_LOAD_STAGE(st + 1 < st1 ? st + 1 : st)
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(0);
+        const int st_ = st + 2 < st1 ? st + 2 : st1 - 1;       // tile loaded during this step
+        float* Ap_ = As + ((buf ^ 1) * TK + lrow) * TM + col4 * 4;
+        float* Bp_ = Bs + ((buf ^ 1) * TK + lrow) * TN + col4 * 4;
         const float* Ab = As + (buf * TK + fh) * TM + wm * 64 + fi;
         const float* Bb = Bs + (buf * TK + fh) * TN + wn * 64 + fi;
+        float2 fa[2], fb[2];
+        fa[0] = *reinterpret_cast<const float2*>(Ab);
+        fb[0] = *reinterpret_cast<const float2*>(Bb);
 #pragma unroll
         for (int kk = 0; kk < TK / 2; ++kk) {
-            const float2 fa = *reinterpret_cast<const float2*>(Ab + kk * 2 * TM);
-            const float2 fb = *reinterpret_cast<const float2*>(Bb + kk * 2 * TN);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc[1][1], 0, 0, 0);
+            const int cur = kk & 1;
+            if (kk + 1 < TK / 2) {
+                fa[cur ^ 1] = *reinterpret_cast<const float2*>(Ab + (kk + 1) * 2 * TM);
+                fb[cur ^ 1] = *reinterpret_cast<const float2*>(Bb + (kk + 1) * 2 * TN);
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].x, fb[cur].x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].x, fb[cur].y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].y, fb[cur].x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].y, fb[cur].y, acc[1][1], 0, 0, 0);
+            switch (kk) {          // constant after unrolling
+                case 0: WG_STORE(0) break;  case 1: WG_STORE(1) break;  case 2: WG_STORE(2) break;  case 3: WG_STORE(3) break;
+                case 5: amask = 0; bmask = 0; WG_LOAD(0) break;
+                case 7: WG_LOAD(1) break;  case 9: WG_LOAD(2) break;  case 11: WG_LOAD(3) break;
+                default: break;
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-        WG_STORE_STAGE(buf ^ 1)
         __syncthreads();
     }
-    __builtin_amdgcn_s_setprio(0);
 #undef WG_LOAD
 #undef WG_LOAD_STAGE
 #undef WG_STORE
@@ -222,12 +233,20 @@ void plan(const ssdhip_wgrad_params* p, WgradArgs& a) {
     a.CoutT = a.CB * TM; a.CinT = a.IB * TN;
     a.dHoWo = make_fastdiv((unsigned)a.HoWo); a.dWo = make_fastdiv((unsigned)a.Wo);
     a.stages = cdiv(a.M, TK);
+    // split-K: the grid runs in rounds of 512 resident blocks (256 CUs x 2); pick the split that minimises
+    // rounds x K-steps per block, plus ~3 K-steps per block for its slab store and share of the reduce pass
     const int tiles = a.CB * a.IB * a.taps;
-    int sk = cdiv(1024, tiles);
-    if (sk > a.stages / 8) sk = a.stages / 8;
-    if (sk < 1) sk = 1;
-    if (sk > 32) sk = 32;
-    a.stages_per_split = cdiv(a.stages, sk);
+    int best_sk = 1;
+    long best_cost = -1;
+    for (int sk = 1; sk <= 32; ++sk) {
+        const int per = cdiv(a.stages, sk);
+        if (sk > 1 && per < 4) break;
+        const int splits = cdiv(a.stages, per);
+        const long rounds = cdiv((long)tiles * splits, 512);
+        const long cost = rounds * (per + 3);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_sk = sk; }
+    }
+    a.stages_per_split = cdiv(a.stages, best_sk);
     a.splitK = cdiv(a.stages, a.stages_per_split);
 }
 
