@@ -210,6 +210,175 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(float* __restrict__ ou
     }
 }
 
+// ---- NMS, workspace variant: the O(K^2) IoU work spread over the whole chip ---------------------------------------------
+//   nms_sort_kernel   per image: candidate keys -> LDS bitonic sort -> sorted prior indices + boxes + count in the workspace
+//   nms_mask_kernel   64-row x 256-column tiles of the upper triangle: lane = column candidate, 64 head rows broadcast by
+//                     shuffle, one __ballot per (row, column chunk) -> bit-matrix mask[n][row][chunk]
+//   nms_scan_kernel   per image: wave 0 walks the sorted candidates; `removed` bits live in registers (3 words per lane),
+//                     rows are prefetched 4 ahead; kept rows are scattered to a flag array, then the block zeroes the
+//                     score columns of every prior that is not kept (utils.py:114)
+struct NmsWs {
+    int* count;            // (N)
+    int* sidx;             // (N, P) sorted prior indices
+    float4* sbox;          // (N, P) boxes in sorted order
+    unsigned char* flag;   // (N, P) keep flags by prior index
+    unsigned long long* mask;   // (N, P, W) W = ceil(P / 64)
+    int W;
+};
+
+__global__ __launch_bounds__(NMS_THREADS) void nms_sort_kernel(const float* __restrict__ outputs, int P, int C, NmsWs ws) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(lds);
+    __shared__ int cnt;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int ROW = 4 + C;
+    const float* out = outputs + (size_t)n * P * ROW;
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    for (int i = tid; i < P; i += NMS_THREADS) {
+        const float* row = out + (size_t)i * ROW;
+        float sc = row[5];
+        for (int c = 6; c < ROW; ++c) sc = fmaxf(sc, row[c]);
+        ws.flag[(size_t)n * P + i] = 0;
+        if (sc > 0.0f) {
+            int slot = atomicAdd(&cnt, 1);
+            keys[slot] = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+        }
+    }
+    __syncthreads();
+    const int K = cnt;
+    int sortn = 64;
+    while (sortn < K) sortn <<= 1;
+    for (int i = K + tid; i < sortn; i += NMS_THREADS) keys[i] = 0ull;
+    __syncthreads();
+    for (int k = 2; k <= sortn; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (sortn >> 1); t += NMS_THREADS) {
+                int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                int l = i | j;
+                unsigned long long a = keys[i], b = keys[l];
+                bool desc = (i & k) == 0;
+                if ((a < b) == desc) { keys[i] = b; keys[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) ws.count[n] = K;
+    for (int i = tid; i < K; i += NMS_THREADS) {
+        const int idx = (int)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull));
+        const float* row = out + (size_t)idx * ROW;
+        ws.sidx[(size_t)n * P + i] = idx;
+        ws.sbox[(size_t)n * P + i] = make_float4(row[0], row[1], row[2], row[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void nms_mask_kernel(int P, float thr, NmsWs ws) {
+    const int n = blockIdx.z, rc = blockIdx.y, cg = blockIdx.x;       // row chunk (64 rows), column group (4 chunks)
+    const int K = ws.count[n];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int cc = cg * 4 + wave;                                      // this wave's column chunk
+    if (rc * 64 >= K || cc < rc || cc * 64 >= K) return;               // upper triangle (incl. diagonal) of live chunks only
+    const float4* sb = ws.sbox + (size_t)n * P;
+    const int j = cc * 64 + lane, i0 = rc * 64;
+    const bool jv = j < K;
+    const float4 bj = jv ? sb[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 bi = (i0 + lane < K) ? sb[i0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned long long mine = 0ull;
+#pragma unroll 8
+    for (int r = 0; r < 64; ++r) {
+        float4 hb;
+        hb.x = __shfl(bi.x, r, 64); hb.y = __shfl(bi.y, r, 64); hb.z = __shfl(bi.z, r, 64); hb.w = __shfl(bi.w, r, 64);
+        const bool hit = jv && (j > i0 + r) && iou_gt(hb, bj, thr);
+        const unsigned long long m = __ballot(hit);
+        if (lane == r) mine = m;
+    }
+    if (i0 + lane < K) ws.mask[((size_t)n * P + i0 + lane) * ws.W + cc] = mine;
+}
+
+__global__ __launch_bounds__(256) void nms_scan_kernel(float* __restrict__ outputs, int P, int C, NmsWs ws, unsigned char* __restrict__ keep_out) {
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int K = ws.count[n];
+    const int ROW = 4 + C;
+    if (tid < 64) {
+        const unsigned long long* mrow = ws.mask + (size_t)n * P * ws.W;
+        const int W = ws.W;                       // row stride in words; <= 192 (P <= 12288): 3 words per lane
+        const int WK = (K + 63) >> 6;             // words the mask kernel actually wrote for this image
+        unsigned long long rem0 = 0, rem1 = 0, rem2 = 0, kept0 = 0, kept1 = 0, kept2 = 0;
+        constexpr int D = 4;                      // rows prefetched ahead of the serial chain
+        unsigned long long p0[D], p1[D], p2[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int i = d;
+            const int first = i >> 6;             // words before the row's own chunk are never written (and never needed)
+            p0[d] = (i < K && lane < WK && lane >= first) ? mrow[(size_t)i * W + lane] : 0ull;
+            p1[d] = (i < K && lane + 64 < WK && lane + 64 >= first) ? mrow[(size_t)i * W + lane + 64] : 0ull;
+            p2[d] = (i < K && lane + 128 < WK && lane + 128 >= first) ? mrow[(size_t)i * W + lane + 128] : 0ull;
+        }
+        for (int base = 0; base < K; base += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int i = base + d;
+                if (i < K) {                                                   // uniform
+                    const int wi = i >> 6, owner = wi & 63, reg = wi >> 6;
+                    const unsigned long long rsel = reg == 0 ? rem0 : (reg == 1 ? rem1 : rem2);
+                    const unsigned lo = __builtin_amdgcn_readlane((unsigned)rsel, owner);
+                    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(rsel >> 32), owner);
+                    const unsigned long long word = ((unsigned long long)hi << 32) | lo;
+                    if (!((word >> (i & 63)) & 1ull)) {                        // candidate i survives: it suppresses its row
+                        rem0 |= p0[d]; rem1 |= p1[d]; rem2 |= p2[d];
+                        if (lane == owner) {
+                            const unsigned long long bit = 1ull << (i & 63);
+                            if (reg == 0) kept0 |= bit; else if (reg == 1) kept1 |= bit; else kept2 |= bit;
+                        }
+                    }
+                }
+                const int nx = i + D;
+                const int first = nx >> 6;
+                p0[d] = (nx < K && lane < WK && lane >= first) ? mrow[(size_t)nx * W + lane] : 0ull;
+                p1[d] = (nx < K && lane + 64 < WK && lane + 64 >= first) ? mrow[(size_t)nx * W + lane + 64] : 0ull;
+                p2[d] = (nx < K && lane + 128 < WK && lane + 128 >= first) ? mrow[(size_t)nx * W + lane + 128] : 0ull;
+            }
+        }
+        const int* sidx = ws.sidx + (size_t)n * P;
+        unsigned char* flag = ws.flag + (size_t)n * P;
+#pragma unroll
+        for (int reg = 0; reg < 3; ++reg) {
+            unsigned long long kw = reg == 0 ? kept0 : (reg == 1 ? kept1 : kept2);
+            const int wbase = (lane + 64 * reg) * 64;
+            while (kw) {
+                const int b = __ffsll((long long)kw) - 1;
+                kw &= kw - 1;
+                flag[sidx[wbase + b]] = 1;
+            }
+        }
+    }
+    __syncthreads();
+    float* out = outputs + (size_t)n * P * ROW;
+    const unsigned char* flag = ws.flag + (size_t)n * P;
+    for (int i = tid; i < P; i += 256) {
+        const bool k = flag[i] != 0;
+        if (keep_out) keep_out[(size_t)n * P + i] = k ? 1 : 0;
+        if (!k) {
+            float* row = out + (size_t)i * ROW;
+            for (int c = 4; c < ROW; ++c) row[c] = row[c] * 0.0f;
+        }
+    }
+}
+
+size_t nms_ws_layout(int N, int P, NmsWs* ws, unsigned char* base) {
+    const int W = (P + 63) / 64;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const size_t o_count = take((size_t)N * 4), o_sidx = take((size_t)N * P * 4), o_sbox = take((size_t)N * P * 16);
+    const size_t o_flag = take((size_t)N * P), o_mask = take((size_t)N * P * W * 8);
+    if (ws) {
+        ws->count = reinterpret_cast<int*>(base + o_count); ws->sidx = reinterpret_cast<int*>(base + o_sidx);
+        ws->sbox = reinterpret_cast<float4*>(base + o_sbox); ws->flag = base + o_flag;
+        ws->mask = reinterpret_cast<unsigned long long*>(base + o_mask); ws->W = W;
+    }
+    return off;
+}
+
 }  // namespace
 
 extern "C" {
@@ -227,6 +396,39 @@ int ssdhip_calc_iou(const float* t, const float* s, int N, int T, int S, int row
     SSDHIP_REQUIRE(t && s && iou && N > 0 && T > 0 && S > 0 && rowt >= 4 && rows >= 4, "calc_iou: bad arguments");
     SSDHIP_REQUIRE(T <= 65535 && N <= 65535, "calc_iou: T and N must be <= 65535");
     hipLaunchKernelGGL(calc_iou_kernel, dim3(cdiv(S, 256), T, N), dim3(256), 0, (hipStream_t)stream, t, s, T, S, rowt, rows, iou);
+    SSDHIP_CHECK_LAUNCH();
+    return SSDHIP_OK;
+}
+
+int64_t ssdhip_nms_ws_bytes(int N, int P) {
+    if (N <= 0 || P <= 0) return SSDHIP_EINVAL;
+    return (int64_t)nms_ws_layout(N, P, nullptr, nullptr);
+}
+
+int ssdhip_nms_ws(float* outputs, int N, int P, int C, float iou_thresh, uint8_t* keep, void* ws_ptr, void* stream) {
+    SSDHIP_REQUIRE(outputs && ws_ptr && N > 0 && P > 0 && C >= 2, "nms_ws: bad arguments");
+    SSDHIP_REQUIRE(P <= 12288, "nms_ws: P <= 12288 (three 64-bit words of suppression state per lane)");
+    SSDHIP_REQUIRE(N <= 65535, "nms_ws: N <= 65535");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                128 * 1024) != hipSuccess) {
+            ssdhip_set_error("nms_ws: cannot enable 128 KiB dynamic LDS");
+            return SSDHIP_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    NmsWs ws;
+    nms_ws_layout(N, P, &ws, reinterpret_cast<unsigned char*>(ws_ptr));
+    hipStream_t st = (hipStream_t)stream;
+    int sortn = 64;
+    while (sortn < P) sortn <<= 1;
+    hipLaunchKernelGGL(nms_sort_kernel, dim3(N), dim3(NMS_THREADS), (size_t)sortn * 8, st, outputs, P, C, ws);
+    SSDHIP_CHECK_LAUNCH();
+    const int chunks = (P + 63) / 64;
+    hipLaunchKernelGGL(nms_mask_kernel, dim3((chunks + 3) / 4, chunks, N), dim3(256), 0, st, P, iou_thresh, ws);
+    SSDHIP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(N), dim3(256), 0, st, outputs, P, C, ws, keep);
     SSDHIP_CHECK_LAUNCH();
     return SSDHIP_OK;
 }

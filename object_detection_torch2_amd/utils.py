@@ -69,16 +69,31 @@ def calc_iou(t: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def non_maximum_suppression(outputs: torch.Tensor, iou_thresh: float = 0.5, return_keep: bool = False) -> torch.Tensor:
+_nms_ws = {}
+
+
+def non_maximum_suppression(outputs: torch.Tensor, iou_thresh: float = 0.5, return_keep: bool = False, variant: str = 'auto') -> torch.Tensor:
     """utils.py:80-116: greedy class-agnostic NMS; zeroes outputs[:, :, 4:] of suppressed / void rows IN PLACE and
-    returns `outputs` (the same object), like the reference."""
+    returns `outputs` (the same object), like the reference.
+    variant: 'lds' (one workgroup per image, everything in LDS), 'ws' (bit-matrix over the whole chip + serial scan,
+    cached workspace) or 'auto' (ws for P <= 12288)."""
     _lib.require_gpu(outputs)
     if outputs.dim() != 3 or outputs.shape[2] < 6:
         raise ValueError(f'expected (N, P, 4 + C) with C >= 2, got {tuple(outputs.shape)}')
     work = outputs if (outputs.is_contiguous() and outputs.dtype == torch.float32) else _lib.f32c(outputs).clone()
     N, P, row = work.shape
     keep = torch.empty(N, P, dtype=torch.uint8, device=work.device)
-    _lib.check(_lib.load().ssdhip_nms(_lib.ptr(work), N, P, row - 4, float(iou_thresh), _lib.ptr(keep), _lib.stream()), 'nms')
+    lib = _lib.load()
+    if variant == 'ws' or (variant == 'auto' and P <= 12288):
+        key = (N, P, str(work.device))
+        ws = _nms_ws.get(key)
+        if ws is None:
+            ws = torch.empty(lib.ssdhip_nms_ws_bytes(N, P), dtype=torch.uint8, device=work.device)
+            _nms_ws.clear()
+            _nms_ws[key] = ws
+        _lib.check(lib.ssdhip_nms_ws(_lib.ptr(work), N, P, row - 4, float(iou_thresh), _lib.ptr(keep), _lib.ptr(ws), _lib.stream()), 'nms')
+    else:
+        _lib.check(lib.ssdhip_nms(_lib.ptr(work), N, P, row - 4, float(iou_thresh), _lib.ptr(keep), _lib.stream()), 'nms')
     if work is not outputs:
         outputs.copy_(work)
     return (outputs, keep) if return_keep else outputs

@@ -130,11 +130,12 @@ def test_decode_score_nms(env, golden, tag, bias, seed):
     assert ((sc > 0).sum(dim=2) == 1).all()
     # NMS kernel on the ORACLE's decoded boxes: keep set must be identical to the reference's
     pre = np.concatenate([O.calc_coordicate(raw, env['df']), O.calc_score(raw)], axis=2)
-    t = torch.from_numpy(pre).to(DEV)
-    ret, keep = utils.non_maximum_suppression(t, return_keep=True)
-    assert ret is t                                                   # in place, same object (utils.py:114-116)
     ref_keep = unpack(fx[tag + '_keep_bits'], (2, 8732))
-    assert np.array_equal(keep.cpu().numpy().astype(bool), ref_keep)
+    for variant in ('lds', 'ws'):                                     # all-LDS kernel and the chip-wide bit-matrix variant
+        t = torch.from_numpy(pre).to(DEV)
+        ret, keep = utils.non_maximum_suppression(t, return_keep=True, variant=variant)
+        assert ret is t                                               # in place, same object (utils.py:114-116)
+        assert np.array_equal(keep.cpu().numpy().astype(bool), ref_keep), variant
     post = t.cpu().numpy()
     assert np.array_equal(post[:, :, :4], pre[:, :, :4])
     assert np.array_equal(post[:, :, 4:], pre[:, :, 4:] * ref_keep[..., None])
@@ -160,11 +161,12 @@ def test_nms_edge_cases(env):
     o[1, 17, 4] = 0.0; o[1, 17, 9] = 0.7
     o[2, :100, 4] = 0.0
     o[2, :100, 6] = torch.linspace(0.9, 0.1, 100, device=DEV)
-    out, keep = utils.non_maximum_suppression(o, return_keep=True)
-    keep = keep.cpu().numpy()
-    assert keep[0].sum() == 0 and (out[0, :, 4:] == 0).all()
-    assert keep[1].sum() == 1 and keep[1, 17] == 1 and out[1, 17, 9].item() == pytest.approx(0.7)
-    assert keep[2].sum() == 1 and keep[2, 0] == 1
+    for variant in ('lds', 'ws'):
+        out, keep = utils.non_maximum_suppression(o.clone(), return_keep=True, variant=variant)
+        keep = keep.cpu().numpy()
+        assert keep[0].sum() == 0 and (out[0, :, 4:] == 0).all()
+        assert keep[1].sum() == 1 and keep[1, 17] == 1 and out[1, 17, 9].item() == pytest.approx(0.7)
+        assert keep[2].sum() == 1 and keep[2, 0] == 1
     with pytest.raises(ValueError):
         utils.non_maximum_suppression(torch.zeros(1, 10, 5, device=DEV))
 
