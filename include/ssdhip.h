@@ -121,7 +121,7 @@ int ssdhip_calc_iou(const float* t, const float* s, int N, int T, int S, int row
  * keep (N,P) uint8 (optional, may be NULL).  P <= 16384.                                                    */
 int ssdhip_nms(float* outputs, int N, int P, int C, float iou_thresh, uint8_t* keep, void* stream);
 /* same result with a caller workspace (ssdhip_nms_ws_bytes): sort per image, IoU bit-matrix over the whole chip, serial
- * scan per image on register-resident suppression bits.  P <= 12288.  Preferred for batches (the LDS-only variant keeps one
+ * scan per image on register-resident suppression bits.  P <= 9984.  Preferred for batches (the LDS-only variant keeps one
  * CU per image busy).                                                                                        */
 int64_t ssdhip_nms_ws_bytes(int N, int P);
 int ssdhip_nms_ws(float* outputs, int N, int P, int C, float iou_thresh, uint8_t* keep, void* ws, void* stream);

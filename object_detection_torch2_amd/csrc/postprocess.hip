@@ -296,60 +296,82 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(int P, float thr, NmsWs w
 }
 
 __global__ __launch_bounds__(256) void nms_scan_kernel(float* __restrict__ outputs, int P, int C, NmsWs ws, unsigned char* __restrict__ keep_out) {
-    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    // Greedy chain over the precomputed bit-matrix, 64 candidates (one mask word) per batch:
+    //   waves 0-2  lane l of wave w owns suppression word 64w + l ("removed" bits of candidates 64*(64w+l) ..) in a register
+    //   wave 3     streams the next batch of 64 mask rows from the workspace into the other LDS buffer (16 B per lane)
+    //   per batch  wave 0 resolves the 64x64 diagonal block on scalar bitmasks (v_readlane with constant lane, like the LDS
+    //              variant), then every owner lane ORs the rows of the surviving candidates into its word (LDS reads, no
+    //              serial dependency); two barriers per batch, global latency never on the chain
+    extern __shared__ __attribute__((aligned(16))) unsigned long long rows[];     // [2][64][W] + 2 scalars
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = ws.count[n];
     const int ROW = 4 + C;
-    if (tid < 64) {
-        const unsigned long long* mrow = ws.mask + (size_t)n * P * ws.W;
-        const int W = ws.W;                       // row stride in words; <= 192 (P <= 12288): 3 words per lane
-        const int WK = (K + 63) >> 6;             // words the mask kernel actually wrote for this image
-        unsigned long long rem0 = 0, rem1 = 0, rem2 = 0, kept0 = 0, kept1 = 0, kept2 = 0;
-        constexpr int D = 4;                      // rows prefetched ahead of the serial chain
-        unsigned long long p0[D], p1[D], p2[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int i = d;
-            const int first = i >> 6;             // words before the row's own chunk are never written (and never needed)
-            p0[d] = (i < K && lane < WK && lane >= first) ? mrow[(size_t)i * W + lane] : 0ull;
-            p1[d] = (i < K && lane + 64 < WK && lane + 64 >= first) ? mrow[(size_t)i * W + lane + 64] : 0ull;
-            p2[d] = (i < K && lane + 128 < WK && lane + 128 >= first) ? mrow[(size_t)i * W + lane + 128] : 0ull;
+    const int W = ws.W, WK = (K + 63) >> 6;       // row stride in words / words the mask kernel wrote for this image
+    const unsigned long long* mrow = ws.mask + (size_t)n * P * W;
+    unsigned long long* slot = rows + (size_t)2 * 64 * W;      // [0] removed word of the current batch, [1] its survivors
+    const int myword = wave * 64 + lane;                       // waves 0-2
+    unsigned long long rem = 0ull, kept = 0ull;
+
+    // wave 3: rows [64bt, 64bt+64) straight into LDS with LDS-DMA (global_load_lds, 16 B per lane, no VGPR staging, all
+    // 64-128 transfers of a batch in flight at once).  Destination = wave-uniform row base + lane * 16 B, so lanes whose
+    // word pair lies outside [bt, WK) are simply masked off (EXEC) and leave their LDS slot untouched (never read).
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto load_batch = [&](int bt) {
+        unsigned long long* dst = rows + (size_t)(bt & 1) * 64 * W;
+        const int nrows = min(64, K - bt * 64);
+        const int wp0 = 2 * lane, wp1 = 2 * lane + 128;
+        const bool a0 = wp0 + 1 >= bt && wp0 < WK, a1 = wp1 + 1 >= bt && wp1 < WK;
+        for (int r = 0; r < nrows; ++r) {
+            const unsigned long long* g = mrow + (size_t)(bt * 64 + r) * W;
+            if (a0) __builtin_amdgcn_global_load_lds((gptr_t)(g + wp0), (lptr_t)(dst + r * W), 16, 0, 0);
+            if (a1) __builtin_amdgcn_global_load_lds((gptr_t)(g + wp1), (lptr_t)(dst + r * W + 128), 16, 0, 0);
         }
-        for (int base = 0; base < K; base += D) {
+    };
+    if (wave == 3 && WK > 0) load_batch(0);
+    if (tid == 0) slot[0] = 0ull;
+    __syncthreads();
+    for (int bt = 0; bt < WK; ++bt) {
+        const unsigned long long* src = rows + (size_t)(bt & 1) * 64 * W;
+        if (wave == 3) {
+            if (bt + 1 < WK) load_batch(bt + 1);
+        } else if (wave == 0) {
+            const int left = K - bt * 64;
+            const unsigned long long valid = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+            unsigned long long alive = valid & ~slot[0];
+            const unsigned long long diag = src[lane * W + bt];          // row `lane` of the diagonal block
+            const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const int i = base + d;
-                if (i < K) {                                                   // uniform
-                    const int wi = i >> 6, owner = wi & 63, reg = wi >> 6;
-                    const unsigned long long rsel = reg == 0 ? rem0 : (reg == 1 ? rem1 : rem2);
-                    const unsigned lo = __builtin_amdgcn_readlane((unsigned)rsel, owner);
-                    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(rsel >> 32), owner);
-                    const unsigned long long word = ((unsigned long long)hi << 32) | lo;
-                    if (!((word >> (i & 63)) & 1ull)) {                        // candidate i survives: it suppresses its row
-                        rem0 |= p0[d]; rem1 |= p1[d]; rem2 |= p2[d];
-                        if (lane == owner) {
-                            const unsigned long long bit = 1ull << (i & 63);
-                            if (reg == 0) kept0 |= bit; else if (reg == 1) kept1 |= bit; else kept2 |= bit;
-                        }
-                    }
-                }
-                const int nx = i + D;
-                const int first = nx >> 6;
-                p0[d] = (nx < K && lane < WK && lane >= first) ? mrow[(size_t)nx * W + lane] : 0ull;
-                p1[d] = (nx < K && lane + 64 < WK && lane + 64 >= first) ? mrow[(size_t)nx * W + lane + 64] : 0ull;
-                p2[d] = (nx < K && lane + 128 < WK && lane + 128 >= first) ? mrow[(size_t)nx * W + lane + 128] : 0ull;
+            for (int i = 0; i < 64; ++i) {
+                const unsigned lo = __builtin_amdgcn_readlane(dlo, i);
+                const unsigned hi = __builtin_amdgcn_readlane(dhi, i);
+                if ((alive >> i) & 1ull) alive &= ~(((unsigned long long)hi << 32) | lo);
             }
+            if (lane == 0) slot[1] = alive;
         }
+        __syncthreads();
+        if (wave < 3) {
+            unsigned long long kw = slot[1];
+            if (myword == bt) kept = kw;
+            if (myword > bt && myword < WK) {
+                while (kw) {                                              // uniform loop over the survivors of this batch
+                    const int r = __ffsll((long long)kw) - 1;
+                    kw &= kw - 1;
+                    rem |= src[r * W + myword];
+                }
+            }
+            if (myword == bt + 1) slot[0] = rem;
+        }
+        __syncthreads();
+    }
+    if (wave < 3 && kept) {
         const int* sidx = ws.sidx + (size_t)n * P;
         unsigned char* flag = ws.flag + (size_t)n * P;
-#pragma unroll
-        for (int reg = 0; reg < 3; ++reg) {
-            unsigned long long kw = reg == 0 ? kept0 : (reg == 1 ? kept1 : kept2);
-            const int wbase = (lane + 64 * reg) * 64;
-            while (kw) {
-                const int b = __ffsll((long long)kw) - 1;
-                kw &= kw - 1;
-                flag[sidx[wbase + b]] = 1;
-            }
+        unsigned long long kw = kept;
+        while (kw) {
+            const int bb = __ffsll((long long)kw) - 1;
+            kw &= kw - 1;
+            flag[sidx[myword * 64 + bb]] = 1;
         }
     }
     __syncthreads();
@@ -366,7 +388,7 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(float* __restrict__ outpu
 }
 
 size_t nms_ws_layout(int N, int P, NmsWs* ws, unsigned char* base) {
-    const int W = (P + 63) / 64;
+    const int W = ((P + 63) / 64 + 1) / 2 * 2;      // even: mask rows stay 16-B aligned
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     const size_t o_count = take((size_t)N * 4), o_sidx = take((size_t)N * P * 4), o_sbox = take((size_t)N * P * 16);
@@ -407,11 +429,13 @@ int64_t ssdhip_nms_ws_bytes(int N, int P) {
 
 int ssdhip_nms_ws(float* outputs, int N, int P, int C, float iou_thresh, uint8_t* keep, void* ws_ptr, void* stream) {
     SSDHIP_REQUIRE(outputs && ws_ptr && N > 0 && P > 0 && C >= 2, "nms_ws: bad arguments");
-    SSDHIP_REQUIRE(P <= 12288, "nms_ws: P <= 12288 (three 64-bit words of suppression state per lane)");
+    SSDHIP_REQUIRE(P <= 9984, "nms_ws: P <= 9984 (two 64-row batches of the bit-matrix must fit 160 KiB of LDS; 192 word-pair loaders)");
     SSDHIP_REQUIRE(N <= 65535, "nms_ws: N <= 65535");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(nms_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                NMS_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 128 * 1024) != hipSuccess) {
             ssdhip_set_error("nms_ws: cannot enable 128 KiB dynamic LDS");
             return SSDHIP_ELAUNCH;
@@ -428,7 +452,7 @@ int ssdhip_nms_ws(float* outputs, int N, int P, int C, float iou_thresh, uint8_t
     const int chunks = (P + 63) / 64;
     hipLaunchKernelGGL(nms_mask_kernel, dim3((chunks + 3) / 4, chunks, N), dim3(256), 0, st, P, iou_thresh, ws);
     SSDHIP_CHECK_LAUNCH();
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(N), dim3(256), 0, st, outputs, P, C, ws, keep);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(N), dim3(256), (size_t)2 * 64 * ws.W * 8 + 16, st, outputs, P, C, ws, keep);
     SSDHIP_CHECK_LAUNCH();
     return SSDHIP_OK;
 }
