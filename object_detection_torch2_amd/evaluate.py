@@ -18,25 +18,6 @@ from . import synth
 from .model import SSD
 from .utils import LabelMap, calc_iou, decode_score_, non_maximum_suppression
 
-OUTPUT_FORMAT = '''
-# EVALUATION REPORT
-
-## REPORTING DATE
-{date}
-
-## RUNTIME
-```
-{runtime}
-```
-
-## CONFIG
-{config_table}
-
-## SCORES
-{score_table}
-'''
-
-
 def get_order(t: torch.Tensor, class_id: int) -> torch.Tensor:
     """evaluate.py:31-42: indices of rows with a positive score for class_id, by descending score."""
     vals, indices = torch.sort(t[:, 5 + class_id], descending=True)
@@ -53,20 +34,22 @@ def assign_true_positives(iou_one_class: torch.Tensor) -> torch.Tensor:
 
 
 def calc_average_precision(result: torch.Tensor, count, reference_compatible: bool = True) -> torch.Tensor:
-    """evaluate.py:45-67.  result (X, 2) = [is_tp, score]; count = number of GT boxes of the class."""
-    result = result.detach().cpu().float()
+    """AP of one class from rows [is_tp, score] and the number of GT boxes (evaluate.py:45-67).
+    Precision envelope: p*(k) = max_{j >= k} p(j); AP = sum_k p*(k) * (r(k) - r(k-1)), plus the reference's closing
+    segment from the last recall to 1 at precision 0."""
+    import numpy as np
+    rows = result.detach().cpu().numpy().astype(np.float64)
     if reference_compatible:
-        correct = torch.sort(result, dim=0, descending=True).values[:, 0]       # columns sorted independently (Q11)
+        hits = np.sort(rows[:, 0])[::-1]            # the reference sorts each column on its own (Q11): TPs come first
     else:
-        correct = result[torch.argsort(result[:, 1], descending=True, stable=True), 0]
-    tp = torch.cumsum(correct == 1., dim=0)
-    fp = torch.cumsum(correct == 0., dim=0)
-    precision = 1.0 * tp / (tp + fp)
-    recall = 1.0 * tp / count
-    mod_precision = torch.cat([torch.Tensor([0.]), precision, torch.Tensor([0.])])
-    mod_precision = torch.flip(torch.cummax(torch.flip(mod_precision, dims=[0]), dim=0).values, dims=[0])
-    mod_recall = torch.cat([torch.Tensor([0.]), recall, torch.Tensor([1.])])
-    return torch.sum(mod_precision[1:] * (mod_recall[1:] - mod_recall[:-1]))
+        hits = rows[np.argsort(-rows[:, 1], kind='stable'), 0]
+    tp = np.cumsum(hits == 1.0)
+    fp = np.cumsum(hits == 0.0)
+    precision = tp / np.maximum(tp + fp, 1)
+    recall = tp / float(count)
+    envelope = np.maximum.accumulate(precision[::-1])[::-1]
+    steps = np.diff(np.concatenate([[0.0], recall]))
+    return torch.tensor(float(np.sum(envelope * steps)), dtype=torch.float32)
 
 
 def evaluate_batches(net, defaults, batches, num_classes=20):
@@ -119,28 +102,27 @@ def main():
                    torch.from_numpy(synth.targets(4000 + b, args.batch_size)).to(device))
 
     correct, count = evaluate_batches(net, defaults, batches())
-    score_table = ['|label|average precision (reference)|average precision (score-ranked)|', '|-|-|-|']
+    lines = [f'# Evaluation report {date.today().isoformat()}', '', '## Runtime', '```']
+    try:
+        lines.append(check_output(['rocm-smi', '--showproductname', '--showmeminfo', 'vram']).decode().strip())
+    except Exception as e:   # noqa: BLE001  (rocm-smi missing or not permitted)
+        lines.append(f'rocm-smi unavailable: {e}')
+    lines += ['```', '', '## Config', '', '|item|value|', '|-|-|'] + [f'|{k}|{v}|' for k, v in vars(args).items()]
+    lines += ['', '## Scores', '', '|label|AP, reference definition (TPs ranked first)|AP, score-ranked (VOC)|', '|-|-|-|']
     aps = []
     for c in range(20):
         if correct[c] and count[c] > 0:
             rows = torch.cat(correct[c]).cpu()
-            ap_ref = calc_average_precision(rows, count[c], True).item()
-            ap_voc = calc_average_precision(rows, count[c], False).item()
+            pair = (calc_average_precision(rows, count[c], True).item(), calc_average_precision(rows, count[c], False).item())
         else:
-            ap_ref = ap_voc = 0.0
-        aps.append((ap_ref, ap_voc))
-        score_table.append(f'|{labelmap.id2name(c)}|{round(ap_ref, 3)}|{round(ap_voc, 3)}|')
-    score_table.append(f'|**mean**|**{round(sum(a for a, _ in aps) / 20, 3)}**|**{round(sum(b for _, b in aps) / 20, 3)}**|')
-    try:
-        runtime = check_output(['rocm-smi', '--showproductname', '--showmeminfo', 'vram']).decode()
-    except (OSError, Exception) as e:   # noqa: BLE001
-        runtime = f'rocm-smi unavailable: {e}'
-    config_table = ['|item|value|', '|-|-|'] + [f'|{k}|{v}|' for k, v in args.__dict__.items()]
-    d = date.today().isoformat()
-    report = OUTPUT_FORMAT.format(date=d, runtime=runtime, config_table='\n'.join(config_table), score_table='\n'.join(score_table))
-    with open(out_dir / f'report_{d}.md', 'w') as f:
-        f.write(report)
-    print('\n'.join(score_table[-1:]))
+            pair = (0.0, 0.0)
+        aps.append(pair)
+        lines.append(f'|{labelmap.id2name(c)}|{pair[0]:.3f}|{pair[1]:.3f}|')
+    mean = (sum(a for a, _ in aps) / 20, sum(b for _, b in aps) / 20)
+    lines.append(f'|**mean**|**{mean[0]:.3f}**|**{mean[1]:.3f}**|')
+    report = out_dir / f'report_{date.today().isoformat()}.md'
+    report.write_text('\n'.join(lines) + '\n')
+    print(lines[-1])
     print('Finished Evaluate')
 
 
