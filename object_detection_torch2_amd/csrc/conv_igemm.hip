@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWave
     constexpr int WROWS = BM / 2, WCOLS = BN / 2;     // per-wave output tile (wave grid 2 x 2)
     constexpr int MT = WROWS / 32, NT = WCOLS / 32;   // 32x32 MFMA tiles per wave
     constexpr int AL = BM / 32, BL = BN / 32;         // float4 loads per thread per stage (2 or 4)
-    constexpr int GROUPS = 4 * MT * NT;               // groups of 4 MFMAs per K-step
+    constexpr int GROUPS = 4 * MT * NT;               // groups of MFMAs per K-step (4 each; MT*NT each in element-major order)
     constexpr int SLICES = 17;                        // staging slices spread over the groups (see CONV_SLICE)
     __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_ROW];
     float* As = lds;
@@ -228,21 +228,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWave
 #pragma unroll
                 for (int j = 0; j < NT; ++j) fb[cur ^ 1][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_ROW + fko[kc < 3 ? kc + 1 : 0]);
             }
+            // element-major order: consecutive MFMAs hit different accumulators, so a staging instruction slipped between
+            // them never sits on a dependent-accumulator chain (64-cycle latency == issue interval leaves no slack)
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+            for (int el = 0; el < 4; ++el) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fb[cur][j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fb[cur][j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, fb[cur][j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].w, fb[cur][j].w, acc[i][j], 0, 0, 0);
-                    constexpr int dummy = 0; (void)dummy;
-                    const int g = (kc * MT + i) * NT + j;
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const float av = el == 0 ? fa[cur][i].x : el == 1 ? fa[cur][i].y : el == 2 ? fa[cur][i].z : fa[cur][i].w;
+                        const float bv = el == 0 ? fb[cur][j].x : el == 1 ? fb[cur][j].y : el == 2 ? fb[cur][j].z : fb[cur][j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
+                if (MT * NT == 4 || (el & (4 / (MT * NT) - 1)) == 4 / (MT * NT) - 1) {     // one group = 4 MFMAs
+                    const int g = MT * NT == 4 ? kc * 4 + el : MT * NT == 2 ? kc * 2 + (el >> 1) : kc;
 #pragma unroll
                     for (int sl = 0; sl < SLICES; ++sl)
                         if (sl >= g * SLICES / GROUPS && sl < (g + 1) * SLICES / GROUPS) { CONV_SLICE(sl) }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            }
         }
         __syncthreads();
     }

@@ -151,6 +151,8 @@ class Engine:
         b['head_off'], b['P'] = offs, p
         b['partial'] = torch.empty(max_partial, **f)
         b['ws64'] = torch.empty(64 * cmax * 2, device=dev, dtype=torch.float64)
+        if len(self._bufs) >= 3:                 # keep the three most recent batch geometries (≈3.4 GB each at N=32)
+            self._bufs.pop(next(iter(self._bufs)))
         self._bufs[key] = b
         return b
 
