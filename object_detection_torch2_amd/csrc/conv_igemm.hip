@@ -36,6 +36,10 @@ struct ConvArgs {
     float* stats;
     long long y_batch_stride;
     int M, Hi, Wi, Cin, cpt, Ho, Wo, HoWo, Cout, taps, stride, lgStride, pad, KP, KT, MB, NB, accumulate, dense;
+    // iteration space (Ho, Wo) maps to output pixel (oh0 + ostep*h, ow0 + ostep*w) of an OWf-wide image; taps walked are
+    // r = r0 + rstep*ri (ri < nr), s = s0 + rstep*si (si < ns).  Forward and stride-1 dgrad: identity / all taps.  Stride-2
+    // dgrad runs once per output-parity class with only the taps whose source pixel exists (2.25 of 9 on average).
+    int OWf, oh0, ow0, ostep, r0, s0, rstep, nr, ns;
 };
 
 template <int KS>
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWave
                 a_h[i] = ho * a.stride - a.pad; a_w[i] = wo * a.stride - a.pad;
                 a_pix[i] = (n * a.Hi + a_h[i]) * a.Wi + a_w[i];
             } else {
-                a_h[i] = ho + a.pad; a_w[i] = wo + a.pad;
+                a_h[i] = a.oh0 + a.ostep * ho + a.pad; a_w[i] = a.ow0 + a.ostep * wo + a.pad;
                 a_pix[i] = n * a.Hi * a.Wi;
             }
         } else {
@@ -115,11 +119,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWave
     unsigned tapoff, woff_k;
 #define CONV_PREP()                                                                                                   \
     {                                                                                                                 \
-        if (SMALLC) { tap = ld_kt * 8 + col4; c = 0; }                                                                \
-        else { tap = ld_tap; c = ld_cc * BK + col4 * 4; }                                                             \
-        tap_rs<KS>(tap, r, s);                                                                                        \
+        if (SMALLC) { tap = ld_kt * 8 + col4; c = 0; tap_rs<KS>(tap, r, s); woff_k = (unsigned)(ld_kt * BK * 4); }     \
+        else {                                                                                                        \
+            const int ri = a.ns == 3 ? (ld_tap * 11) >> 5 : a.ns == 2 ? ld_tap >> 1 : ld_tap;                         \
+            r = a.r0 + a.rstep * ri; s = a.s0 + a.rstep * (ld_tap - ri * a.ns);                                       \
+            tap = r * KS + s; c = ld_cc * BK + col4 * 4;                                                              \
+            woff_k = (unsigned)((ld_cc * a.taps + tap) * BK * 4);                                                     \
+        }                                                                                                             \
         if (MODE == 0) tapoff = (unsigned)(((r * a.Wi + s) * a.Cin + c) * 4);                                         \
-        woff_k = (unsigned)(ld_kt * BK * 4);                                                                          \
         if (XFORM) {                                                                                                  \
             sc = *reinterpret_cast<const float4*>(a.in_scale + c);                                                    \
             sh = *reinterpret_cast<const float4*>(a.in_shift + c);                                                    \
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWave
         okmask = 0;                                                                                                   \
         if (ld_kt < a.KT - 1) {    /* channel block outer, tap inner: the 9 taps of one 128-B line are consecutive */ \
             ++ld_kt;                                                                                                  \
-            if (++ld_tap == a.taps) { ld_tap = 0; ++ld_cc; }                                                          \
+            if (++ld_tap == a.nr * a.ns) { ld_tap = 0; ++ld_cc; }                                                     \
         }                                                                                                             \
     }
 #define CONV_LOAD_A(I)                                                                                                \
@@ -282,7 +289,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWave
                     else {
                         const int n = m / a.HoWo;
                         const int rem = m - n * a.HoWo;
-                        dst = a.y + (size_t)n * a.y_batch_stride + (size_t)rem * a.Cout + co;
+                        const int hh = rem / a.Wo, ww = rem - hh * a.Wo;
+                        dst = a.y + (size_t)n * a.y_batch_stride + (size_t)((a.oh0 + a.ostep * hh) * a.OWf + a.ow0 + a.ostep * ww) * a.Cout + co;
                     }
                     if (a.accumulate) v += *dst;
                     *dst = v;
@@ -415,6 +423,7 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
     a.stride = p->stride; a.lgStride = ilog2(p->stride); a.pad = p->pad; a.KP = p->KP; a.KT = p->KP / BK;
     a.MB = cdiv(a.M, BM); a.NB = cdiv(p->Cout, BN); a.accumulate = p->accumulate;
     a.dense = p->y_batch_stride == (int64_t)p->Ho * p->Wo * p->Cout;
+    a.OWf = p->Wo; a.oh0 = 0; a.ow0 = 0; a.ostep = 1; a.r0 = 0; a.s0 = 0; a.rstep = 1; a.nr = p->R; a.ns = p->S;
     hipStream_t st = (hipStream_t)stream;
     const bool xf = p->in_scale != nullptr;
     if (p->tile >= 1000000) {   // timing-only ablations of the 128x128 3x3 kernel (scripts/conv_bench.py)
@@ -431,15 +440,31 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
         if (p->R == 3) launch_conv<bm, bn, 3>(a, p->mode, xf, st);          \
         else launch_conv<bm, bn, 1>(a, p->mode, xf, st);                    \
         break;
-    switch (key) {
-        SSDHIP_CONV_CASE(128, 128)
-        SSDHIP_CONV_CASE(128, 64)
-        SSDHIP_CONV_CASE(64, 128)
-        SSDHIP_CONV_CASE(64, 64)
-        default: ssdhip_set_error("conv2d: unsupported tile"); return SSDHIP_ENOSUP;
+    // stride-2 data gradient: one launch per output-parity class, each with only the taps that land on a dy pixel
+    // (tiny layers stay on one masked launch: four launches cost more than the wasted MFMAs; measured at M = 3200)
+    const int classes = (p->mode == 1 && p->stride == 2 && p->R == 3 && (int64_t)p->N * p->Ho * p->Wo >= 8192) ? 4 : 1;
+    for (int cls = 0; cls < classes; ++cls) {
+        if (classes == 4) {
+            const int ph = cls >> 1, pw = cls & 1;                       // parity of (ho + pad), (wo + pad)
+            const int h0 = (ph + p->pad) & 1, w0 = (pw + p->pad) & 1;     // first output row / column of the class
+            const int Hc = (p->Ho - h0 + 1) / 2, Wc = (p->Wo - w0 + 1) / 2;
+            if (Hc <= 0 || Wc <= 0) continue;
+            a.Ho = Hc; a.Wo = Wc; a.HoWo = Hc * Wc; a.M = p->N * Hc * Wc;
+            a.oh0 = h0; a.ow0 = w0; a.ostep = 2; a.OWf = p->Wo; a.dense = 0;
+            a.rstep = 2; a.r0 = ph; a.nr = ph == 0 ? 2 : 1; a.s0 = pw; a.ns = pw == 0 ? 2 : 1;
+            a.KT = a.cpt * a.nr * a.ns;
+            a.MB = cdiv(a.M, BM);
+        }
+        switch (key) {
+            SSDHIP_CONV_CASE(128, 128)
+            SSDHIP_CONV_CASE(128, 64)
+            SSDHIP_CONV_CASE(64, 128)
+            SSDHIP_CONV_CASE(64, 64)
+            default: ssdhip_set_error("conv2d: unsupported tile"); return SSDHIP_ENOSUP;
+        }
+        SSDHIP_CHECK_LAUNCH();
     }
 #undef SSDHIP_CONV_CASE
-    SSDHIP_CHECK_LAUNCH();
     return SSDHIP_OK;
 }
 
