@@ -136,8 +136,9 @@ def main():
     if eng.prof:
         agg = {}
         for r in eng.prof:
-            a = agg.setdefault(r['kernel'], dict(ms=0.0, flops=0.0, n=0, layers=set()))
+            a = agg.setdefault(r['kernel'], dict(ms=0.0, flops=0.0, n=0, layers=set(), direct=0.0))
             a['ms'] += r['e0'].elapsed_time(r['e1']); a['flops'] += r['flops']; a['n'] += 1; a['layers'].add(r['layer'])
+            a['direct'] += r.get('direct_flops', r['flops'])
         name, a = max(agg.items(), key=lambda kv: kv[1]['ms'])
         ach = a['flops'] / (a['ms'] * 1e-3) / 1e12
         traffic = None       # HBM-side bytes per launch from the committed PMC passes (scripts/collect_pmc.sh + pmc_summary.py)
@@ -149,6 +150,8 @@ def main():
         roof = dict(bound='mfma', kernel=name, achieved=round(ach, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                     frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic, launches=a['n'],
                     algorithmic_flop_per_launch=round(a['flops'] / a['n']),
+                    note=('achieved/frac count the MFMA flops this kernel executes; the Winograd-domain GEMMs stand for '
+                          f"{a['direct'] / a['flops']:.2f}x as many direct-convolution flops") if a['direct'] > a['flops'] * 1.01 else None,
                     avg_launch_ms=round(a['ms'] / a['n'], 4), layers=sorted(a['layers']),
                     all_conv_fwd_tflops=round(sum(v['flops'] for v in agg.values()) / (sum(v['ms'] for v in agg.values()) * 1e-3) / 1e12, 2))
     eng.prof = None

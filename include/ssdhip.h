@@ -73,12 +73,26 @@ typedef struct {
     int32_t mode;           /* 0 fwd gather, 1 dgrad gather (x = dy, roles of Hi/Ho swapped by caller) */
     int32_t accumulate;     /* 1: y += result (second dgrad contribution)                        */
     int32_t tile;           /* 0 auto, else BM*1000+BN (128128, 128064, 064128, 064064)          */
+    int32_t rows_per_img;   /* 0, or batched-GEMM use: output rows per weight plane (multiple of 128) */
+    int64_t w_img_stride;   /* floats between consecutive weight planes (with rows_per_img)      */
 } ssdhip_conv_params;
 int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream);
 /* m-block size the auto/explicit tile choice will use for `stats` (rows of the partial table = ceil(M/BM)) */
 int ssdhip_conv2d_block_m(const ssdhip_conv_params* p);
 /* BM*1000+BN the call will run with (profiling / bench bookkeeping) */
 int ssdhip_conv2d_tile(const ssdhip_conv_params* p);
+
+/* ---- A3 (deep 3x3 / stride 1 / pad 1 layers)  Winograd F(2x2,3x3) around the same GEMM kernel: 2.25x fewer MFMA flops.
+ * T = N*ceil(H/2)*ceil(W/2) tiles, Tp = T rounded up to 128.  V and M are (16, Tp, C) fp32 planes.
+ *   weight:  U (16, rows_pad, KP) = G g G^T per (co, ci), zero padded
+ *   input:   V = B^T d B of every 4x4 patch, producer BN scale/shift + ReLU fused on load (in_scale may be NULL)
+ *   GEMM:    ssdhip_conv2d_nhwc with N=16, Hi=Ho=1, Wi=Wo=Tp, R=S=1, w_img_stride = rows_pad*KP, rows_per_img = Tp
+ *   output:  y (N,H,W,Cout) = A^T m A + bias, BN partial sums (rows, Cout, 2); returns the number of partial rows     */
+int ssdhip_winograd_tiles(int N, int H, int W, int* T, int* Tp);
+int ssdhip_winograd_weight(const float* w_oihw, float* U, int Cout, int Cin, int rows_pad, int KP, void* stream);
+int ssdhip_winograd_input(const float* x, const float* in_scale, const float* in_shift, float* V, int N, int H, int W, int C,
+                          void* stream);
+int ssdhip_winograd_output(const float* M, const float* bias, float* y, float* stats, int N, int H, int W, int Cout, void* stream);
 
 /* ---- A4  nn.BatchNorm2d, training=True (model/vgg16.py:34, model/ssd.py:62) -----------------------------
  * partial (MB,C,2) -> scale = gamma*rsqrt(var+eps), shift = beta-mean*scale (biased var); running stats EMA with

@@ -21,7 +21,8 @@ class ConvParams(Structure):
                 ('N', c_int32), ('Hi', c_int32), ('Wi', c_int32), ('Cin', c_int32),
                 ('Ho', c_int32), ('Wo', c_int32), ('Cout', c_int32),
                 ('R', c_int32), ('S', c_int32), ('stride', c_int32), ('pad', c_int32),
-                ('KP', c_int32), ('mode', c_int32), ('accumulate', c_int32), ('tile', c_int32)]
+                ('KP', c_int32), ('mode', c_int32), ('accumulate', c_int32), ('tile', c_int32),
+                ('rows_per_img', c_int32), ('w_img_stride', c_int64)]
 
 
 class WgradParams(Structure):
@@ -41,6 +42,10 @@ SIGNATURES = {
     'ssdhip_conv2d_nhwc': (c_int, [POINTER(ConvParams), c_void_p]),
     'ssdhip_conv2d_block_m': (c_int, [POINTER(ConvParams)]),
     'ssdhip_conv2d_tile': (c_int, [POINTER(ConvParams)]),
+    'ssdhip_winograd_tiles': (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    'ssdhip_winograd_weight': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'ssdhip_winograd_input': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'ssdhip_winograd_output': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'ssdhip_bn_finalize': (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'ssdhip_bn_fold_eval': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),

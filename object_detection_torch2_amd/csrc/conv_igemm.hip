@@ -40,6 +40,13 @@ struct ConvArgs {
     // r = r0 + rstep*ri (ri < nr), s = s0 + rstep*si (si < ns).  Forward and stride-1 dgrad: identity / all taps.  Stride-2
     // dgrad runs once per output-parity class with only the taps whose source pixel exists (2.25 of 9 on average).
     int OWf, oh0, ow0, ostep, r0, s0, rstep, nr, ns;
+    // batched GEMM use (Winograd domain): block rows m0.. belong to plane m0 / rows_per_img, whose weights start w_img_stride
+    // floats further (rows_per_img is a multiple of the m-tile so no tile straddles two planes); 0 = one weight matrix
+    long long w_img_stride;
+    int rows_per_img;
+    // persistent plane-GEMM blocks: each block walks tpb consecutive m-tiles of one n-tile as ONE software pipeline (the loads
+    // of the next tile's first K-steps are in flight during the current tile's last MFMAs and its stores); 1 = one tile per block
+    int tpb;
 };
 
 template <int KS>
@@ -69,11 +76,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWave
     // XCD-aware bijective tile order (blocks b, b+8, ... share an XCD)
     int t;
     {
-        const int T = a.MB * a.NB, bid = blockIdx.x;
+        const int T = ((a.MB + a.tpb - 1) / a.tpb) * a.NB, bid = blockIdx.x;
         const int xcd = bid & 7, local = bid >> 3, q = T >> 3, r = T & 7;
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
     }
-    const int mt_idx = t / a.NB, nt_idx = t - mt_idx * a.NB;
+    const int mchunk = t / a.NB, nt_idx = t - mchunk * a.NB;
+    const int mt_idx = mchunk * a.tpb;                         // first m-tile of this block
+    const int ntl = min(a.tpb, a.MB - mt_idx);                 // m-tiles this block walks
     const int m0 = mt_idx * BM, n0 = nt_idx * BN;
 
     // ---- per-thread gather state: AL rows of the A tile, fixed 16-B column slot --------------------------------
@@ -81,6 +90,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWave
     const int lrow = tid >> 3, col4 = tid & 7;
     const char* xb = reinterpret_cast<const char*>(a.x);
     const char* wb = reinterpret_cast<const char*>(a.w);
+    if (a.rows_per_img > 0) wb += (size_t)(m0 / a.rows_per_img) * (size_t)a.w_img_stride * 4;
+    int ld_tile = 0;                       // loader's m-tile within the block (persistent plane-GEMM mode)
+    bool ld_wrap = false;
     int a_h[4], a_w[4], a_pix[4];          // MODE 0: a_pix = pixel index of tap (0,0); MODE 1: image base pixel
     unsigned w_off[4];
 #pragma unroll
@@ -119,6 +131,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWave
     unsigned tapoff, woff_k;
 #define CONV_PREP()                                                                                                   \
     {                                                                                                                 \
+        if (ld_wrap) {             /* the loader enters the block's next m-tile (rows + BM, maybe the next weight plane) */ \
+            ld_wrap = false; ++ld_tile;                                                                               \
+            a_pix[0] += BM; a_pix[1] += BM; a_pix[2] += BM; a_pix[3] += BM;                                           \
+            wb = reinterpret_cast<const char*>(a.w) + (size_t)((m0 + ld_tile * BM) / a.rows_per_img) * (size_t)a.w_img_stride * 4; \
+        }                                                                                                             \
         if (SMALLC) { tap = ld_kt * 8 + col4; c = 0; tap_rs<KS>(tap, r, s); woff_k = (unsigned)(ld_kt * BK * 4); }     \
         else {                                                                                                        \
             const int ri = a.ns == 3 ? (ld_tap * 11) >> 5 : a.ns == 2 ? ld_tap >> 1 : ld_tap;                         \
@@ -135,7 +152,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWave
         if (ld_kt < a.KT - 1) {    /* channel block outer, tap inner: the 9 taps of one 128-B line are consecutive */ \
             ++ld_kt;                                                                                                  \
             if (++ld_tap == a.nr * a.ns) { ld_tap = 0; ++ld_cc; }                                                     \
-        }                                                                                                             \
+        } else if (ld_tile + 1 < ntl) { ld_kt = 0; ld_tap = 0; ld_cc = 0; ld_wrap = true; }                           \
     }
 #define CONV_LOAD_A(I)                                                                                                \
     if (AL > I) {                                                                                                     \
@@ -215,7 +232,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWave
     for (int kc = 0; kc < 4; ++kc) fko[kc] = ((2 * kc + fh) ^ fx) * 4;
     const float* Afr = As + (wm * WROWS + frow) * LDS_ROW;
     const float* Bfr = Bs + (wn * WCOLS + frow) * LDS_ROW;
-    for (int kt = 0; kt < a.KT; ++kt) {
+    const int total_steps = ntl * a.KT;
+    int kt_in = 0, m_cur = m0;             // K-step inside the current m-tile, first row of that tile
+    for (int kt = 0; kt < total_steps; ++kt) {
         const int buf = kt & 1;
         Ast_ = As + (buf ^ 1) * BM * LDS_ROW + lrow * LDS_ROW + st_chunk;
         Bst_ = Bs + (buf ^ 1) * BN * LDS_ROW + lrow * LDS_ROW + st_chunk;
@@ -256,8 +275,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWave
                 }
             }
         }
+        if (a.tpb > 1) {           // persistent plane-GEMM: a finished m-tile is stored from inside the pipeline (dense rows)
+            if (++kt_in == a.KT) {
+                kt_in = 0;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int co = n0 + wn * WCOLS + j * 32 + (lane & 31);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int m = m_cur + wm * WROWS + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                            if (co < a.Cout) a.y[(size_t)m * a.Cout + co] = acc[i][j][e];
+                            acc[i][j][e] = 0.f;
+                        }
+                }
+                m_cur += BM;
+            }
+        }
         __syncthreads();
     }
+    if (a.tpb > 1) return;
 #undef CONV_PREP
 #undef CONV_LOAD_A
 #undef CONV_LOAD_B
@@ -369,7 +407,7 @@ int choose_tile(const ssdhip_conv_params* p, int& BM, int& BN) {
 
 template <int BM, int BN, int KS>
 void launch_conv(const ConvArgs& a, int mode, bool xform, hipStream_t st) {
-    dim3 grid(a.MB * a.NB), block(256);
+    dim3 grid(cdiv(a.MB, a.tpb) * a.NB), block(256);
     if (a.Cin == 4) {
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, KS, 0, false, true>), grid, block, 0, st, a);
     } else if (mode == 0) {
@@ -415,6 +453,8 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
     }
     int BM, BN;
     SSDHIP_REQUIRE(choose_tile(p, BM, BN) == SSDHIP_OK, "conv2d: tile must be one of 128128/128064/64128/64064");
+    SSDHIP_REQUIRE(p->rows_per_img == 0 || (p->rows_per_img % BM == 0 && p->mode == 0 && p->w_img_stride > 0),
+                   "conv2d: rows_per_img must be a multiple of the m-tile (batched GEMM use)");
     ConvArgs a;
     a.x = p->x; a.w = p->w; a.bias = p->bias; a.in_scale = p->in_scale; a.in_shift = p->in_shift; a.y = p->y; a.stats = p->stats;
     a.y_batch_stride = p->y_batch_stride;
@@ -423,6 +463,16 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
     a.stride = p->stride; a.lgStride = ilog2(p->stride); a.pad = p->pad; a.KP = p->KP; a.KT = p->KP / BK;
     a.MB = cdiv(a.M, BM); a.NB = cdiv(p->Cout, BN); a.accumulate = p->accumulate;
     a.dense = p->y_batch_stride == (int64_t)p->Ho * p->Wo * p->Cout;
+    a.w_img_stride = p->w_img_stride; a.rows_per_img = p->rows_per_img;
+    a.tpb = 1;
+    if (p->rows_per_img > 0 && !p->bias && !p->stats && !p->accumulate && p->R == 1 && !p->in_scale && a.M % BM == 0 &&
+        p->y_batch_stride == (int64_t)p->Ho * p->Wo * p->Cout) {
+        // short-K plane GEMMs: amortise pipeline fill/drain over several m-tiles, but keep >= ~6 blocks per CU
+        const int64_t tiles = (int64_t)a.MB * a.NB;
+        a.tpb = (int)(tiles / (256 * 6));
+        if (a.tpb < 1) a.tpb = 1;
+        if (a.tpb > 8) a.tpb = 8;
+    }
     a.OWf = p->Wo; a.oh0 = 0; a.ow0 = 0; a.ostep = 1; a.r0 = 0; a.s0 = 0; a.rstep = 1; a.nr = p->R; a.ns = p->S;
     hipStream_t st = (hipStream_t)stream;
     const bool xf = p->in_scale != nullptr;

@@ -36,6 +36,12 @@ class _ConvSpec:
         self.packed_key = None
         self.packed_d = None
         self.packed_d_key = None
+        # Winograd F(2x2,3x3) forward for the deep 3x3/s1/p1 layers (conv_3_1 .. conv_6_1): measured x1.1 .. x1.8 over the
+        # direct kernel (scripts/wino_bench.py); the wide, shallow layers (conv_1_x, conv_2_x) lose to the transform traffic
+        self.wino = (not is_head and k == 3 and stride == 1 and pad == 1 and cin % 32 == 0 and cin >= 128
+                     and cout % 4 == 0 and 256 % (cout // 4) == 0)
+        self.wino_u = None
+        self.wino_key = None
 
 
 class _Stage:
@@ -149,12 +155,66 @@ class Engine:
                 offs.append(p)
                 p += g['ho'] * g['wo'] * s.head.anchors
         b['head_off'], b['P'] = offs, p
+        wino_v = wino_m = 0
+        for s, g in zip(self.stages, geo):
+            if s.conv.wino and self._wino_ok(g):
+                tp = (N * ((g['hi'] + 1) // 2) * ((g['wi'] + 1) // 2) + 127) // 128 * 128
+                wino_v, wino_m = max(wino_v, 16 * tp * s.conv.cin), max(wino_m, 16 * tp * s.conv.cout)
+        b['wino_v'] = torch.empty(wino_v, **f) if wino_v else None
+        b['wino_m'] = torch.empty(wino_m, **f) if wino_m else None
         b['partial'] = torch.empty(max_partial, **f)
         b['ws64'] = torch.empty(64 * cmax * 2, device=dev, dtype=torch.float64)
         if len(self._bufs) >= 3:                 # keep the three most recent batch geometries (≈3.4 GB each at N=32)
             self._bufs.pop(next(iter(self._bufs)))
         self._bufs[key] = b
         return b
+
+    @staticmethod
+    def _wino_ok(g):
+        return g['hi'] <= 160 and g['wi'] <= 160        # from the 150x150 maps down (x1.1 there, x1.8 at 38x38); 300x300 is transform-traffic-bound
+
+    def _wino_weights(self, spec):
+        w, _ = self._weight(spec)
+        key = (w.data_ptr(), w._version, self.m._hip_epoch if not spec.frozen else 0)
+        if spec.wino_u is None or spec.wino_u.device != w.device:
+            spec.wino_u = torch.empty(16 * spec.rows_pad * spec.cin, device=w.device, dtype=torch.float32)
+            spec.wino_key = None
+        if spec.wino_key != key:
+            _lib.check(self.lib.ssdhip_winograd_weight(_lib.ptr(w), _lib.ptr(spec.wino_u), spec.cout, spec.cin, spec.rows_pad, spec.cin,
+                                                       _lib.stream()), 'winograd_weight')
+            spec.wino_key = key
+        return spec.wino_u
+
+    def _conv_winograd(self, spec, x, xs, z, b, N, h, w, stats):
+        """3x3/s1/p1 conv as input transform -> 16 plane GEMMs (one launch of the implicit-GEMM kernel) -> output transform.
+        Returns the number of BN partial rows written to `stats`."""
+        L, st = self.lib, _lib.stream()
+        U = self._wino_weights(spec)
+        _, bias = self._weight(spec)
+        V, Mo = b['wino_v'], b['wino_m']
+        tp = (N * ((h + 1) // 2) * ((w + 1) // 2) + 127) // 128 * 128
+        _lib.check(L.ssdhip_winograd_input(_lib.ptr(x), _lib.ptr(xs[0]) if xs is not None else None,
+                                           _lib.ptr(xs[1]) if xs is not None else None, _lib.ptr(V), N, h, w, spec.cin, st), f'winograd_input {spec.name}')
+        p = _lib.ConvParams()
+        p.x, p.w, p.y, p.y_batch_stride = V.data_ptr(), U.data_ptr(), Mo.data_ptr(), tp * spec.cout
+        p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout = 16, 1, tp, spec.cin, 1, tp, spec.cout
+        p.R, p.S, p.stride, p.pad, p.KP, p.mode, p.accumulate = 1, 1, 1, 0, spec.cin, 0, 0
+        # measured (scripts/wino_bench.py): 128x128 tiles once the grid has > 2000 of them, 64x128 below
+        p.tile = 128128 if (16 * tp // 128) * ((spec.cout + 127) // 128) > 2000 else 64128
+        p.rows_per_img, p.w_img_stride = tp, spec.rows_pad * spec.cin
+        if self.prof is None:
+            _lib.check(L.ssdhip_conv2d_nhwc(ctypes.byref(p), st), f'winograd gemm {spec.name}')
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(L.ssdhip_conv2d_nhwc(ctypes.byref(p), st), f'winograd gemm {spec.name}')
+            e1.record()
+            self.prof.append(dict(layer=spec.name + ' (winograd-domain GEMM)',
+                                  kernel='conv_igemm_kernel<%d, 128, 1, 0, false, false, 0>' % (p.tile // 1000),
+                                  direct_flops=2.0 * N * h * w * spec.cin * spec.cout * 9,
+                                  flops=2.0 * 16 * tp * spec.cin * spec.cout, e0=e0, e1=e1))
+        return _lib.check(L.ssdhip_winograd_output(_lib.ptr(Mo), _lib.ptr(bias), _lib.ptr(z), _lib.ptr(stats), N, h, w, spec.cout, st),
+                          f'winograd_output {spec.name}')
 
     def _conv(self, spec, x, xs, y, y_batch_stride, N, hi, wi, ho, wo, stats, tile=0):
         w = self._pack(spec)
@@ -210,12 +270,16 @@ class Engine:
             z = b['z'][i]
             M = N * g['ho'] * g['wo']
             bst = self._bn_state(s.bn_name, c.cout, dev)
-            bm = self._conv(c, cur, cur_xs, z.data_ptr(), g['ho'] * g['wo'] * c.cout, N, g['hi'], g['wi'], g['ho'], g['wo'],
-                            b['partial'] if training else None)
+            if c.wino and self._wino_ok(g):
+                rows = self._conv_winograd(c, cur, cur_xs, z, b, N, g['hi'], g['wi'], b['partial'] if training else None)
+            else:
+                bm = self._conv(c, cur, cur_xs, z.data_ptr(), g['ho'] * g['wo'] * c.cout, N, g['hi'], g['wi'], g['ho'], g['wo'],
+                                b['partial'] if training else None)
+                rows = (M + bm - 1) // bm
             if training:
                 track = bnm.track_running_stats and bnm.running_mean is not None
                 mom = 0.1 if bnm.momentum is None else bnm.momentum
-                _lib.check(self.lib.ssdhip_bn_finalize(_lib.ptr(b['partial']), (M + bm - 1) // bm, c.cout, M, _lib.ptr(bnm.weight),
+                _lib.check(self.lib.ssdhip_bn_finalize(_lib.ptr(b['partial']), rows, c.cout, M, _lib.ptr(bnm.weight),
                                                        _lib.ptr(bnm.bias), _lib.ptr(bnm.running_mean) if track else None,
                                                        _lib.ptr(bnm.running_var) if track else None, mom, bnm.eps,
                                                        _lib.ptr(bst['scale']), _lib.ptr(bst['shift']), _lib.ptr(bst['mean']),

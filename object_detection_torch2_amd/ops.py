@@ -150,3 +150,35 @@ def to_nhwc(x_nchw, pad_to=None):
     if pad_to and x.shape[-1] < pad_to:
         x = torch.cat([x, x.new_zeros(*x.shape[:-1], pad_to - x.shape[-1])], dim=-1).contiguous()
     return x
+
+
+def conv3x3_winograd(x, w_oihw, bias=None, in_scale=None, in_shift=None, want_stats=False, tile=0):
+    """3x3 / stride 1 / pad 1 convolution through the Winograd F(2x2,3x3) passes.  x (N,H,W,Cin) NHWC, Cin % 32 == 0.
+    Returns (z (N,H,W,Cout), stats (rows,Cout,2) or None)."""
+    _lib.require_gpu(x, w_oihw)
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    cout, cin, k, _ = w_oihw.shape
+    if k != 3 or cin != C or C % 32:
+        raise ValueError('conv3x3_winograd: 3x3 kernels, Cin % 32 == 0')
+    T, Tp = ctypes.c_int(), ctypes.c_int()
+    _lib.check(lib.ssdhip_winograd_tiles(N, H, W, ctypes.byref(T), ctypes.byref(Tp)), 'winograd_tiles')
+    T, Tp = T.value, Tp.value
+    rows_pad = _rup(cout, 128)
+    dev = x.device
+    U = torch.empty(16 * rows_pad * C, device=dev, dtype=torch.float32)
+    V = torch.empty(16 * Tp * C, device=dev, dtype=torch.float32)
+    Mo = torch.empty(16 * Tp * cout, device=dev, dtype=torch.float32)
+    z = torch.empty(N, H, W, cout, device=dev, dtype=torch.float32)
+    st = _lib.stream()
+    _lib.check(lib.ssdhip_winograd_weight(_lib.ptr(_lib.f32c(w_oihw)), _lib.ptr(U), cout, cin, rows_pad, C, st), 'winograd_weight')
+    _lib.check(lib.ssdhip_winograd_input(_lib.ptr(x), _lib.ptr(in_scale), _lib.ptr(in_shift), _lib.ptr(V), N, H, W, C, st), 'winograd_input')
+    p = _lib.ConvParams()
+    p.x, p.w, p.y, p.y_batch_stride = V.data_ptr(), U.data_ptr(), Mo.data_ptr(), Tp * cout
+    p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout = 16, 1, Tp, C, 1, Tp, cout
+    p.R, p.S, p.stride, p.pad, p.KP, p.mode, p.accumulate, p.tile = 1, 1, 1, 0, C, 0, 0, tile
+    p.rows_per_img, p.w_img_stride = Tp, rows_pad * C
+    _lib.check(lib.ssdhip_conv2d_nhwc(ctypes.byref(p), st), 'winograd gemm')
+    stats = torch.empty((T + 63) // 64, cout, 2, device=dev, dtype=torch.float32) if want_stats else None
+    _lib.check(lib.ssdhip_winograd_output(_lib.ptr(Mo), _lib.ptr(bias), _lib.ptr(z), _lib.ptr(stats), N, H, W, cout, st), 'winograd_output')
+    return z, stats

@@ -107,6 +107,8 @@ BWD_CASES = [
     (2, 19, 19, 128, 256, 1, 1, 0),     # conv_8_1 style
     (2, 19, 19, 128, 256, 3, 2, 1),     # conv_8_2 style (stride 2, odd input)
     (2, 10, 10, 128, 256, 3, 2, 1),     # conv_9_2 style (stride 2, even input)
+    (32, 19, 19, 32, 64, 3, 2, 1),      # stride 2, M >= 8192: dgrad runs as four output-parity classes (odd input)
+    (24, 20, 20, 32, 64, 3, 2, 1),      # same, even input
     (2, 5, 5, 128, 256, 3, 1, 0),       # conv_10_2
     (2, 3, 3, 128, 256, 3, 1, 0),       # conv_11_2
     (2, 19, 19, 128, 150, 3, 1, 1),     # detector head: dy channels padded 150 -> 160
@@ -170,3 +172,32 @@ def test_bn_relu_backward():
     assert rel_err(dz.permute(0, 3, 1, 2).cpu(), z.grad) < 5e-5
     assert rel_err(dgamma.cpu(), bn.weight.grad) < 5e-5
     assert rel_err(dbeta.cpu(), bn.bias.grad) < 5e-5
+
+
+# (N, H, W, Cin, Cout): odd and even maps, Cout 256 / 512 / 1024 (output-transform lane layouts 4 / 2 / 1 tile lanes)
+WINO_CASES = [(2, 19, 19, 64, 256), (2, 10, 10, 96, 512), (1, 7, 9, 32, 1024), (3, 38, 38, 64, 256)]
+
+
+@pytest.mark.parametrize('case', WINO_CASES)
+def test_conv3x3_winograd(case):
+    """Winograd F(2x2,3x3) passes vs F.conv2d, incl. the fused BN+ReLU input transform (zero padding after it), bias and
+    the BatchNorm partial sums.  fp32; the transforms add a few ulp over the direct kernel: 1e-4 relative."""
+    from object_detection_torch2_amd import ops
+    N, H, W, cin, cout = case
+    zprev = rnd(N, cin, H, W, seed=31)
+    scale, shift = rnd(cin, seed=32), rnd(cin, seed=33) + 0.5
+    w = rnd(cout, cin, 3, 3, seed=34, scale=(2.0 / (cin * 9)) ** 0.5)
+    b = rnd(cout, seed=35)
+    a = F.relu(zprev * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    ref = F.conv2d(a, w, b, padding=1)
+    z, stats = ops.conv3x3_winograd(ops.to_nhwc(zprev.to(DEV)), w.to(DEV), b.to(DEV), in_scale=scale.to(DEV), in_shift=shift.to(DEV),
+                                    want_stats=True)
+    got = z.permute(0, 3, 1, 2).cpu()
+    assert rel_err(got, ref) < 1e-4
+    s = stats.sum(dim=0).cpu()
+    assert torch.allclose(s[:, 0], ref.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(s[:, 1], (ref * ref).sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
+    # plain input (layer after a pool), no bias
+    ref2 = F.conv2d(zprev, w, None, padding=1)
+    z2, _ = ops.conv3x3_winograd(ops.to_nhwc(zprev.to(DEV)), w.to(DEV))
+    assert rel_err(z2.permute(0, 3, 1, 2).cpu(), ref2) < 1e-4
