@@ -153,6 +153,10 @@ typedef struct {
 } ssdhip_wgrad_params;
 int64_t ssdhip_conv2d_wgrad_ws_bytes(const ssdhip_wgrad_params* p);
 int ssdhip_conv2d_wgrad(const ssdhip_wgrad_params* p, void* stream);
+/* same result for 3x3 / stride 1 / pad 1 layers through Winograd F(2x2,3x3): V = B^T d B (input, fused BN+ReLU), dM = A dY A^T,
+ * 16 plane products dU = dM^T V on the wgrad MFMA kernel (2.25x fewer flops), dW = G^T dU G.  dy must be dense.     */
+int64_t ssdhip_conv2d_wgrad_winograd_ws_bytes(const ssdhip_wgrad_params* p);
+int ssdhip_conv2d_wgrad_winograd(const ssdhip_wgrad_params* p, void* stream);
 
 /* BatchNorm2d(train)+ReLU backward.  z raw conv output (M,C); da grad w.r.t. relu output.
  * pass 1: partial sums of dy=da*(z*scale+shift>0) and dy*xhat -> (MB,C,2);  pass 2 (after finalize):

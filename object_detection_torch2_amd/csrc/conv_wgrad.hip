@@ -37,6 +37,10 @@ struct WgradArgs {
     int M, Hi, Wi, Cin, Ho, Wo, HoWo, Cout, CoutRow, KS, taps, stride, pad;
     int CB, IB, splitK, stages_per_split, stages, CoutT, CinT;
     FastDiv dHoWo, dWo;
+    // Winograd-domain use: `tap` indexes one of 16 planes; plane p's operands start p * stride floats further and the rows
+    // are plain (no spatial gather): the geometry fields are set to a 1 x Tp image by the host
+    long long x_plane_stride, dy_plane_stride;
+    int plane_mode;
 };
 
 template <bool XFORM>
@@ -53,7 +57,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tap = b % a.taps; b /= a.taps;
     const int split = b;
     const int co0 = cb * TM, ci0 = ib * TN;
-    const int r = tap / a.KS, s = tap - r * a.KS;
+    const int r = a.plane_mode ? 0 : tap / a.KS, s = a.plane_mode ? 0 : tap - r * a.KS;
+    const float* xbase = a.x + (a.plane_mode ? (size_t)tap * a.x_plane_stride : (size_t)0);
+    const float* dybase = a.dy + (a.plane_mode ? (size_t)tap * a.dy_plane_stride : (size_t)0);
 
     const int lrow = tid >> 5, col4 = tid & 31;     // 8 rows x 32 float4 per pass, 4 passes
     const int st0 = split * a.stages_per_split;
@@ -85,8 +91,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const bool bok = mok && ci_ok && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi;              \
         const size_t aoff = aok ? (size_t)n * a.dy_batch_stride + (size_t)rem * a.CoutRow + co : (size_t)0;           \
         const size_t boff = bok ? ((size_t)(n * a.Hi + hi) * a.Wi + wi) * a.Cin + ci : (size_t)0;                     \
-        ra##I = *reinterpret_cast<const float4*>(a.dy + aoff);                                                        \
-        rb##I = *reinterpret_cast<const float4*>(a.x + boff);                                                         \
+        ra##I = *reinterpret_cast<const float4*>(dybase + aoff);                                                      \
+        rb##I = *reinterpret_cast<const float4*>(xbase + boff);                                                       \
         amask |= (aok ? 1u : 0u) << I;                                                                                \
         bmask |= (bok ? 1u : 0u) << I;                                                                                \
     }
@@ -224,15 +230,78 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, int MB, i
     out[c] = (float)s;
 }
 
-void plan(const ssdhip_wgrad_params* p, WgradArgs& a) {
-    a.x = p->x; a.dy = p->dy; a.in_scale = p->in_scale; a.in_shift = p->in_shift; a.ws = p->ws;
-    a.dy_batch_stride = p->dy_batch_stride;
-    a.M = p->N * p->Ho * p->Wo; a.Hi = p->Hi; a.Wi = p->Wi; a.Cin = p->Cin; a.Ho = p->Ho; a.Wo = p->Wo; a.HoWo = p->Ho * p->Wo;
-    a.Cout = p->Cout; a.CoutRow = p->dy_row; a.KS = p->S; a.taps = p->R * p->S; a.stride = p->stride; a.pad = p->pad;
-    a.CB = cdiv(p->Cout, TM); a.IB = cdiv(p->Cin, TN);
-    a.CoutT = a.CB * TM; a.CinT = a.IB * TN;
-    a.dHoWo = make_fastdiv((unsigned)a.HoWo); a.dWo = make_fastdiv((unsigned)a.Wo);
-    a.stages = cdiv(a.M, TK);
+// ---- Winograd F(2x2,3x3) weight gradient (3x3 / stride 1 / pad 1 layers): dU[xi] = sum_t dM[xi][t]^T V[xi][t], 2.25x fewer flops ----
+// dM[xi][t][co] = (A dY A^T)[xi] of every 2x2 output-gradient tile, A = [[1,0],[1,1],[1,-1],[0,-1]]; zero outside the image
+__global__ __launch_bounds__(256) void winograd_outgrad_kernel(const float4* __restrict__ dy, float4* __restrict__ dM, int H, int W,
+                                                               int C4, int TH, int TW, int T, int Tp) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)T * C4) return;
+    const int c4 = (int)(idx % C4);
+    const int t = (int)(idx / C4);
+    const int tw = t % TW;
+    const int q = t / TW;
+    const int th = q % TH;
+    const int n = q / TH;
+    float4 y[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int h = 2 * th + i, w = 2 * tw + j;
+            y[i][j] = (h < H && w < W) ? dy[((size_t)(n * H + h) * W + w) * C4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    auto add = [](float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
+    auto sub = [](float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); };
+    auto neg = [](float4 a) { return make_float4(-a.x, -a.y, -a.z, -a.w); };
+    float4 r[4][2];                                   // A dY
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        r[0][j] = y[0][j]; r[1][j] = add(y[0][j], y[1][j]); r[2][j] = sub(y[0][j], y[1][j]); r[3][j] = neg(y[1][j]);
+    }
+    const size_t plane = (size_t)Tp * C4;
+    float4* o = dM + (size_t)t * C4 + c4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                     // (A dY) A^T
+        o[(size_t)(4 * i + 0) * plane] = r[i][0];
+        o[(size_t)(4 * i + 1) * plane] = add(r[i][0], r[i][1]);
+        o[(size_t)(4 * i + 2) * plane] = sub(r[i][0], r[i][1]);
+        o[(size_t)(4 * i + 3) * plane] = neg(r[i][1]);
+    }
+}
+
+// dW[co][ci][3][3] = G^T (sum_split dU) G,  G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]];  slabs ws[split][co][xi][ci]
+__global__ void winograd_wgrad_output_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int CoutT, int CinT,
+                                             int splitK) {
+    const int64_t total = (int64_t)Cout * Cin;
+    const size_t slab = (size_t)CoutT * 16 * CinT;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin), co = (int)(i / Cin);
+        float u[4][4];
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {
+            const size_t src = ((size_t)co * 16 + xi) * CinT + ci;
+            float v = 0.f;
+            for (int s = 0; s < splitK; ++s) v += ws[s * slab + src];
+            u[xi >> 2][xi & 3] = v;
+        }
+        float t[3][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            t[0][c] = u[0][c] + 0.5f * (u[1][c] + u[2][c]);
+            t[1][c] = 0.5f * (u[1][c] - u[2][c]);
+            t[2][c] = 0.5f * (u[1][c] + u[2][c]) + u[3][c];
+        }
+        float* o = dw + ((size_t)co * Cin + ci) * 9;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            o[r * 3 + 0] = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
+            o[r * 3 + 1] = 0.5f * (t[r][1] - t[r][2]);
+            o[r * 3 + 2] = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
+        }
+    }
+}
+
+void choose_split(WgradArgs& a) {
     // split-K: the grid runs in rounds of 512 resident blocks (256 CUs x 2); pick the split that minimises
     // rounds x K-steps per block, plus ~3 K-steps per block for its slab store and share of the reduce pass
     const int tiles = a.CB * a.IB * a.taps;
@@ -248,6 +317,33 @@ void plan(const ssdhip_wgrad_params* p, WgradArgs& a) {
     }
     a.stages_per_split = cdiv(a.stages, best_sk);
     a.splitK = cdiv(a.stages, a.stages_per_split);
+}
+
+// plane-mode plan: 16 planes of (T x CoutRow)^T (T x Cin) products over Tp-row planes
+void plan_winograd(const ssdhip_wgrad_params* p, WgradArgs& a, int T, int Tp, float* V, float* dM, float* slabs) {
+    a.x = V; a.dy = dM; a.in_scale = nullptr; a.in_shift = nullptr; a.ws = slabs;
+    a.dy_batch_stride = 0;
+    a.M = T; a.Hi = 1; a.Wi = Tp; a.Cin = p->Cin; a.Ho = 1; a.Wo = Tp; a.HoWo = Tp;
+    a.Cout = p->Cout; a.CoutRow = p->dy_row; a.KS = 1; a.taps = 16; a.stride = 1; a.pad = 0;
+    a.CB = cdiv(p->Cout, TM); a.IB = cdiv(p->Cin, TN);
+    a.CoutT = a.CB * TM; a.CinT = a.IB * TN;
+    a.dHoWo = make_fastdiv((unsigned)a.HoWo); a.dWo = make_fastdiv((unsigned)a.Wo);
+    a.stages = cdiv(a.M, TK);
+    a.plane_mode = 1; a.x_plane_stride = (long long)Tp * p->Cin; a.dy_plane_stride = (long long)Tp * p->dy_row;
+    choose_split(a);
+}
+
+void plan(const ssdhip_wgrad_params* p, WgradArgs& a) {
+    a.x = p->x; a.dy = p->dy; a.in_scale = p->in_scale; a.in_shift = p->in_shift; a.ws = p->ws;
+    a.dy_batch_stride = p->dy_batch_stride;
+    a.M = p->N * p->Ho * p->Wo; a.Hi = p->Hi; a.Wi = p->Wi; a.Cin = p->Cin; a.Ho = p->Ho; a.Wo = p->Wo; a.HoWo = p->Ho * p->Wo;
+    a.Cout = p->Cout; a.CoutRow = p->dy_row; a.KS = p->S; a.taps = p->R * p->S; a.stride = p->stride; a.pad = p->pad;
+    a.CB = cdiv(p->Cout, TM); a.IB = cdiv(p->Cin, TN);
+    a.CoutT = a.CB * TM; a.CinT = a.IB * TN;
+    a.dHoWo = make_fastdiv((unsigned)a.HoWo); a.dWo = make_fastdiv((unsigned)a.Wo);
+    a.stages = cdiv(a.M, TK);
+    a.plane_mode = 0; a.x_plane_stride = 0; a.dy_plane_stride = 0;
+    choose_split(a);
 }
 
 }  // namespace
@@ -290,6 +386,67 @@ int ssdhip_conv2d_wgrad(const ssdhip_wgrad_params* p, void* stream) {
         MB = cdiv(a.M, rows_per_block);
         hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(p->Cout, 64), MB), dim3(256), 0, st, p->dy, (long long)p->dy_batch_stride,
                            a.HoWo, (int64_t)a.M, p->Cout, p->dy_row, rows_per_block, partial);
+        SSDHIP_CHECK_LAUNCH();
+        hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(p->Cout, 64)), dim3(64), 0, st, partial, MB, p->Cout, p->dbias);
+        SSDHIP_CHECK_LAUNCH();
+    }
+    return SSDHIP_OK;
+}
+
+static int wino_geometry(const ssdhip_wgrad_params* p, int* T, int* Tp) {
+    if (!(p->R == 3 && p->S == 3 && p->stride == 1 && p->pad == 1 && p->Ho == p->Hi && p->Wo == p->Wi)) return SSDHIP_EINVAL;
+    return ssdhip_winograd_tiles(p->N, p->Hi, p->Wi, T, Tp);
+}
+
+int64_t ssdhip_conv2d_wgrad_winograd_ws_bytes(const ssdhip_wgrad_params* p) {
+    int T, Tp;
+    if (!p || wino_geometry(p, &T, &Tp) != SSDHIP_OK) return SSDHIP_EINVAL;
+    WgradArgs a;
+    plan_winograd(p, a, T, Tp, nullptr, nullptr, nullptr);
+    int64_t v = (int64_t)16 * Tp * p->Cin * 4, dm = (int64_t)16 * Tp * p->dy_row * 4;
+    int64_t slabs = (int64_t)a.splitK * a.CoutT * 16 * a.CinT * 4, bias = (int64_t)64 * p->Cout * 2 * 4;
+    return v + dm + slabs + bias;
+}
+
+int ssdhip_conv2d_wgrad_winograd(const ssdhip_wgrad_params* p, void* stream) {
+    SSDHIP_REQUIRE(p && p->x && p->dy && p->dw_oihw && p->ws, "wgrad_winograd: null pointer");
+    SSDHIP_REQUIRE(p->Cin % 4 == 0 && p->dy_row % 4 == 0 && p->dy_row >= p->Cout, "wgrad_winograd: Cin and dy_row must be multiples of 4");
+    SSDHIP_REQUIRE(p->dy_batch_stride == (int64_t)p->Ho * p->Wo * p->dy_row, "wgrad_winograd: dy must be dense (N,H,W,dy_row)");
+    int T, Tp;
+    SSDHIP_REQUIRE(wino_geometry(p, &T, &Tp) == SSDHIP_OK, "wgrad_winograd: 3x3 / stride 1 / pad 1 layers only");
+    hipStream_t st = (hipStream_t)stream;
+    float* V = p->ws;
+    float* dM = V + (size_t)16 * Tp * p->Cin;
+    float* slabs = dM + (size_t)16 * Tp * p->dy_row;
+    WgradArgs a;
+    plan_winograd(p, a, T, Tp, V, dM, slabs);
+    // 1. V = B^T d B of the layer input (producer BN scale/shift + ReLU fused on load)
+    int rc = ssdhip_winograd_input(p->x, p->in_scale, p->in_shift, V, p->N, p->Hi, p->Wi, p->Cin, stream);
+    if (rc != SSDHIP_OK) return rc;
+    // 2. dM = A dY A^T of the output gradient
+    const int TH = (p->Hi + 1) / 2, TW = (p->Wi + 1) / 2, C4 = p->dy_row / 4;
+    hipLaunchKernelGGL(winograd_outgrad_kernel, dim3(cdiv((int64_t)T * C4, 256)), dim3(256), 0, st, reinterpret_cast<const float4*>(p->dy),
+                       reinterpret_cast<float4*>(dM), p->Hi, p->Wi, C4, TH, TW, T, Tp);
+    SSDHIP_CHECK_LAUNCH();
+    // 3. 16 plane products on the wgrad MFMA kernel (split-K slabs)
+    hipLaunchKernelGGL(wgrad_kernel<false>, dim3(a.CB * a.IB * a.taps * a.splitK), dim3(256), 0, st, a);
+    SSDHIP_CHECK_LAUNCH();
+    // 4. dW = G^T (sum of slabs) G, OIHW
+    int64_t total = (int64_t)p->Cout * p->Cin;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(winograd_wgrad_output_kernel, dim3(blocks), dim3(256), 0, st, slabs, p->dw_oihw, p->Cout, p->Cin, a.CoutT, a.CinT,
+                       a.splitK);
+    SSDHIP_CHECK_LAUNCH();
+    if (p->dbias) {
+        float* partial = slabs + (size_t)a.splitK * a.CoutT * 16 * a.CinT;
+        const int M = p->N * p->Ho * p->Wo;
+        int MB = cdiv(M, 64);
+        if (MB > 64) MB = 64;
+        const int rows_per_block = cdiv(M, MB);
+        MB = cdiv(M, rows_per_block);
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(p->Cout, 64), MB), dim3(256), 0, st, p->dy, (long long)p->dy_batch_stride,
+                           p->Ho * p->Wo, (int64_t)M, p->Cout, p->dy_row, rows_per_block, partial);
         SSDHIP_CHECK_LAUNCH();
         hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(p->Cout, 64)), dim3(64), 0, st, partial, MB, p->Cout, p->dbias);
         SSDHIP_CHECK_LAUNCH();

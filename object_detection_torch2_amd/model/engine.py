@@ -349,10 +349,17 @@ class Engine:
                 if spec is None or spec.frozen:
                     continue
                 p = self._wgrad_params(spec, N, hi, wi, ho, wo)
-                ws_bytes = max(ws_bytes, self.lib.ssdhip_conv2d_wgrad_ws_bytes(ctypes.byref(p)))
+                fn = self.lib.ssdhip_conv2d_wgrad_winograd_ws_bytes if self._wgrad_wino(spec, hi, wi) else self.lib.ssdhip_conv2d_wgrad_ws_bytes
+                ws_bytes = max(ws_bytes, _lib.check(fn(ctypes.byref(p)), 'wgrad_ws_bytes'))
         bw['wgrad_ws'] = torch.empty((ws_bytes + 3) // 4, **f)
         b['bwd'] = bw
         return bw
+
+    @staticmethod
+    def _wgrad_wino(spec, hi, wi):
+        """Winograd F(2x2,3x3) weight gradient: measured x1.2 .. x1.8 for conv_6_1 and the heads on >= 10x10 maps
+        (scripts/conv_bench.py with BWD=1); tiny maps and narrow inputs stay on the direct kernel."""
+        return spec.k == 3 and spec.stride == 1 and spec.pad == 1 and spec.cin >= 256 and min(hi, wi) >= 10
 
     def _wgrad_params(self, spec, N, hi, wi, ho, wo):
         p = _lib.WgradParams()
@@ -373,7 +380,8 @@ class Engine:
         # reference's autograd holds rounding noise there; the flat buffer slot stays 0 (zeroed at allocation)
         p.dbias = views[prefix + '.bias'].data_ptr() if (spec.is_head and (prefix + '.bias') in views) else None
         p.ws = bw['wgrad_ws'].data_ptr()
-        _lib.check(self.lib.ssdhip_conv2d_wgrad(ctypes.byref(p), _lib.stream()), f'wgrad {spec.name}')
+        fn = self.lib.ssdhip_conv2d_wgrad_winograd if self._wgrad_wino(spec, hi, wi) else self.lib.ssdhip_conv2d_wgrad
+        _lib.check(fn(ctypes.byref(p), _lib.stream()), f'wgrad {spec.name}')
 
     def _dgrad(self, spec, dy, dx, N, hdy, wdy, hin, win, accumulate):
         w = self._pack(spec, dgrad=True)

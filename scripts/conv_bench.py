@@ -63,6 +63,9 @@ if os.environ.get('BWD'):
         fl = 2.0 * N * ho * ho * cout * cin * k * k
         t = timeit(lambda: ops.conv2d_wgrad(x, dy, (cout, cin, k, k), stride=stride, pad=pad, in_scale=sc, in_shift=sh))
         line = f'{name:9s} wgrad {t:8.3f} ms {fl/t/1e9:7.1f} TF/s'
+        if k == 3 and stride == 1 and pad == 1:
+            tw = timeit(lambda: ops.conv2d_wgrad(x, dy, (cout, cin, k, k), stride=stride, pad=pad, in_scale=sc, in_shift=sh, winograd=True))
+            line += f' (winograd {tw:.3f} ms)'
         if dg:
             t = timeit(lambda: ops.conv2d_dgrad(dy, w, (H, H), stride=stride, pad=pad))
             line += f' | dgrad {t:8.3f} ms {fl/t/1e9:7.1f} TF/s'

@@ -201,3 +201,30 @@ def test_conv3x3_winograd(case):
     ref2 = F.conv2d(zprev, w, None, padding=1)
     z2, _ = ops.conv3x3_winograd(ops.to_nhwc(zprev.to(DEV)), w.to(DEV))
     assert rel_err(z2.permute(0, 3, 1, 2).cpu(), ref2) < 1e-4
+
+
+# (N, H, W, Cin, Cout): conv_6_1-like and detector-head-like (Cout padded 150 -> 160, 100 -> 128), odd / even maps
+WINO_WGRAD_CASES = [(2, 19, 19, 64, 128), (2, 10, 10, 128, 150), (3, 7, 9, 64, 100), (1, 38, 38, 64, 100)]
+
+
+@pytest.mark.parametrize('case', WINO_WGRAD_CASES)
+def test_wgrad_winograd(case):
+    """Winograd F(2x2,3x3) weight gradient vs autograd, with the fused BN+ReLU input transform and the bias gradient."""
+    from object_detection_torch2_amd import ops
+    N, H, W, cin, cout = case
+    zprev = rnd(N, cin, H, W, seed=41)
+    scale, shift = rnd(cin, seed=42), rnd(cin, seed=43) + 0.3
+    w = rnd(cout, cin, 3, 3, seed=44, scale=0.05).requires_grad_(True)
+    b = torch.zeros(cout, requires_grad=True)
+    a = F.relu(zprev * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    y = F.conv2d(a, w, b, padding=1)
+    dy = rnd(*y.shape, seed=45)
+    y.backward(dy)
+    cpad = (cout + 31) // 32 * 32
+    dw, db = ops.conv2d_wgrad(ops.to_nhwc(zprev.to(DEV)), ops.to_nhwc(dy.to(DEV), pad_to=cpad), tuple(w.shape), pad=1,
+                              in_scale=scale.to(DEV), in_shift=shift.to(DEV), winograd=True)
+    assert rel_err(dw.cpu(), w.grad) < 5e-5
+    assert rel_err(db.cpu(), b.grad) < 2e-5
+    dw2, _ = ops.conv2d_wgrad(ops.to_nhwc(zprev.to(DEV)), ops.to_nhwc(dy.to(DEV), pad_to=cpad), tuple(w.shape), pad=1,
+                              in_scale=scale.to(DEV), in_shift=shift.to(DEV))
+    assert rel_err(dw.cpu(), dw2.cpu()) < 5e-5           # Winograd and direct wgrad agree
