@@ -93,6 +93,10 @@ int ssdhip_winograd_weight(const float* w_oihw, float* U, int Cout, int Cin, int
 int ssdhip_winograd_input(const float* x, const float* in_scale, const float* in_shift, float* V, int N, int H, int W, int C,
                           void* stream);
 int ssdhip_winograd_output(const float* M, const float* bias, float* y, float* stats, int N, int H, int W, int Cout, void* stream);
+/* detector heads: M planes have Cp = Cout padded to 32 channels; y is the (N, P, 4+C) prediction tensor at the head's prior
+ * offset: element (n,h,w,co) at y[n*y_batch_stride + (h*W+w)*Cout + co]  (model/ssd.py:103-104)                          */
+int ssdhip_winograd_output_head(const float* M, const float* bias, float* y, int64_t y_batch_stride, int N, int H, int W, int Cout,
+                                int Cp, void* stream);
 
 /* ---- A4  nn.BatchNorm2d, training=True (model/vgg16.py:34, model/ssd.py:62) -----------------------------
  * partial (MB,C,2) -> scale = gamma*rsqrt(var+eps), shift = beta-mean*scale (biased var); running stats EMA with
@@ -150,6 +154,8 @@ typedef struct {
     int64_t dy_batch_stride;  /* floats between images in dy (Ho*Wo*dy_row when dense)          */
     int32_t N, Hi, Wi, Cin, Ho, Wo, Cout, R, S, stride, pad;
     int32_t dy_row;           /* floats per pixel row of dy (>= Cout, multiple of 4; channel padding) */
+    int32_t reserved;
+    const float* wino_v;      /* Winograd variant only: precomputed input transform V (16,Tp,Cin) of x, or NULL */
 } ssdhip_wgrad_params;
 int64_t ssdhip_conv2d_wgrad_ws_bytes(const ssdhip_wgrad_params* p);
 int ssdhip_conv2d_wgrad(const ssdhip_wgrad_params* p, void* stream);

@@ -29,7 +29,8 @@ class WgradParams(Structure):
     _fields_ = [('x', c_void_p), ('dy', c_void_p), ('in_scale', c_void_p), ('in_shift', c_void_p),
                 ('dw_oihw', c_void_p), ('dbias', c_void_p), ('ws', c_void_p), ('dy_batch_stride', c_int64),
                 ('N', c_int32), ('Hi', c_int32), ('Wi', c_int32), ('Cin', c_int32), ('Ho', c_int32), ('Wo', c_int32),
-                ('Cout', c_int32), ('R', c_int32), ('S', c_int32), ('stride', c_int32), ('pad', c_int32), ('dy_row', c_int32)]
+                ('Cout', c_int32), ('R', c_int32), ('S', c_int32), ('stride', c_int32), ('pad', c_int32), ('dy_row', c_int32),
+                ('reserved', c_int32), ('wino_v', c_void_p)]
 
 
 # every symbol include/ssdhip.h declares: name -> (restype, argtypes)
@@ -46,6 +47,7 @@ SIGNATURES = {
     'ssdhip_winograd_weight': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'ssdhip_winograd_input': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'ssdhip_winograd_output': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'ssdhip_winograd_output_head': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ssdhip_bn_finalize': (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'ssdhip_bn_fold_eval': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),

@@ -415,14 +415,17 @@ int ssdhip_conv2d_wgrad_winograd(const ssdhip_wgrad_params* p, void* stream) {
     int T, Tp;
     SSDHIP_REQUIRE(wino_geometry(p, &T, &Tp) == SSDHIP_OK, "wgrad_winograd: 3x3 / stride 1 / pad 1 layers only");
     hipStream_t st = (hipStream_t)stream;
-    float* V = p->ws;
-    float* dM = V + (size_t)16 * Tp * p->Cin;
+    // V may be handed in (the forward's input transform of the same activation); the workspace keeps its V region either way
+    float* V = p->wino_v ? const_cast<float*>(p->wino_v) : p->ws;
+    float* dM = p->ws + (size_t)16 * Tp * p->Cin;
     float* slabs = dM + (size_t)16 * Tp * p->dy_row;
     WgradArgs a;
     plan_winograd(p, a, T, Tp, V, dM, slabs);
     // 1. V = B^T d B of the layer input (producer BN scale/shift + ReLU fused on load)
-    int rc = ssdhip_winograd_input(p->x, p->in_scale, p->in_shift, V, p->N, p->Hi, p->Wi, p->Cin, stream);
-    if (rc != SSDHIP_OK) return rc;
+    if (!p->wino_v) {
+        int rc = ssdhip_winograd_input(p->x, p->in_scale, p->in_shift, V, p->N, p->Hi, p->Wi, p->Cin, stream);
+        if (rc != SSDHIP_OK) return rc;
+    }
     // 2. dM = A dY A^T of the output gradient
     const int TH = (p->Hi + 1) / 2, TW = (p->Wi + 1) / 2, C4 = p->dy_row / 4;
     hipLaunchKernelGGL(winograd_outgrad_kernel, dim3(cdiv((int64_t)T * C4, 256)), dim3(256), 0, st, reinterpret_cast<const float4*>(p->dy),

@@ -139,6 +139,56 @@ __global__ __launch_bounds__(256) void winograd_output_kernel(const float4* __re
     }
 }
 
+// Detector-head output transform: M (16, Tp, Cp) with Cp = Cout padded to 32 -> y[n*y_batch_stride + (h*W + w)*Cout + co]
+// (the (N, P, 4+C) prediction tensor: zero-copy concat of model/ssd.py:103-104), + bias.  One thread = one tile x 4 channels.
+__global__ __launch_bounds__(256) void winograd_output_head_kernel(const float4* __restrict__ Mo, const float* __restrict__ bias,
+                                                                   float* __restrict__ y, long long y_batch_stride, int H, int W,
+                                                                   int Cout, int Cp4, int TH, int TW, int T, int Tp) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)T * Cp4) return;
+    const int c4 = (int)(idx % Cp4);
+    const int t = (int)(idx / Cp4);
+    if (c4 * 4 >= Cout) return;
+    const int tw = t % TW;
+    const int q = t / TW;
+    const int th = q % TH;
+    const int n = q / TH;
+    const size_t plane = (size_t)Tp * Cp4;
+    const float4* mp = Mo + (size_t)t * Cp4 + c4;
+    float4 m[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[i][j] = mp[(size_t)(4 * i + j) * plane];
+    float4 r[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[0][j] = f4add(f4add(m[0][j], m[1][j]), m[2][j]);
+        r[1][j] = f4sub(f4sub(m[1][j], m[2][j]), m[3][j]);
+    }
+    float bv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bv[k] = (bias && c4 * 4 + k < Cout) ? bias[c4 * 4 + k] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int h = 2 * th + a;
+        if (h >= H) continue;
+        const float4 o0 = f4add(f4add(r[a][0], r[a][1]), r[a][2]);
+        const float4 o1 = f4sub(f4sub(r[a][1], r[a][2]), r[a][3]);
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) {
+            const int w = 2 * tw + b2;
+            if (w >= W) continue;
+            const float4 o = b2 == 0 ? o0 : o1;
+            float* dst = y + (size_t)n * y_batch_stride + (size_t)(h * W + w) * Cout + c4 * 4;
+            const float ov[4] = {o.x + bv[0], o.y + bv[1], o.z + bv[2], o.w + bv[3]};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (c4 * 4 + k < Cout) dst[k] = ov[k];
+        }
+    }
+}
+
 // U[xi][co][ci] = (G g G^T)[xi],  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
 __global__ void winograd_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int rows_pad, int KP) {
     const int64_t total = (int64_t)rows_pad * KP;
@@ -224,6 +274,18 @@ int ssdhip_winograd_output(const float* Mo, const float* bias, float* y, float* 
                        H, W, Cout / 4, TH, TW, T, Tp);
     SSDHIP_CHECK_LAUNCH();
     return cdiv(T, WINO_TB);      // rows of the BN partial table
+}
+
+int ssdhip_winograd_output_head(const float* Mo, const float* bias, float* y, int64_t y_batch_stride, int N, int H, int W, int Cout,
+                                int Cp, void* stream) {
+    SSDHIP_REQUIRE(Mo && y && Cout > 0 && Cp >= Cout && Cp % 4 == 0, "winograd_output_head: bad arguments");
+    int T, Tp;
+    SSDHIP_REQUIRE(ssdhip_winograd_tiles(N, H, W, &T, &Tp) == SSDHIP_OK, "winograd_output_head: bad shape");
+    const int TH = (H + 1) / 2, TW = (W + 1) / 2, Cp4 = Cp / 4;
+    hipLaunchKernelGGL(winograd_output_head_kernel, dim3(cdiv((int64_t)T * Cp4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(Mo), bias, y, (long long)y_batch_stride, H, W, Cout, Cp4, TH, TW, T, Tp);
+    SSDHIP_CHECK_LAUNCH();
+    return SSDHIP_OK;
 }
 
 }  // extern "C"

@@ -40,6 +40,9 @@ class _ConvSpec:
         # direct kernel (scripts/wino_bench.py); the wide, shallow layers (conv_1_x, conv_2_x) lose to the transform traffic
         self.wino = (not is_head and k == 3 and stride == 1 and pad == 1 and cin % 32 == 0 and cin >= 128
                      and cout % 4 == 0 and 256 % (cout // 4) == 0)
+        # detector heads on >= 10x10 maps with wide inputs also run forward through Winograd; their input transform V is kept
+        # and reused by the Winograd weight gradient in backward
+        self.wino_head = is_head and k == 3 and stride == 1 and pad == 1 and cin >= 256
         self.wino_u = None
         self.wino_key = None
 
@@ -160,6 +163,12 @@ class Engine:
             if s.conv.wino and self._wino_ok(g):
                 tp = (N * ((g['hi'] + 1) // 2) * ((g['wi'] + 1) // 2) + 127) // 128 * 128
                 wino_v, wino_m = max(wino_v, 16 * tp * s.conv.cin), max(wino_m, 16 * tp * s.conv.cout)
+        b['head_v'] = {}
+        for i, (s, g) in enumerate(zip(self.stages, geo)):
+            if s.head is not None and s.head.wino_head and min(g['ho'], g['wo']) >= 10:
+                tp = (N * ((g['ho'] + 1) // 2) * ((g['wo'] + 1) // 2) + 127) // 128 * 128
+                b['head_v'][i] = torch.empty(16 * tp * s.head.cin, **f)
+                wino_m = max(wino_m, 16 * tp * s.head.co_pad)
         b['wino_v'] = torch.empty(wino_v, **f) if wino_v else None
         b['wino_m'] = torch.empty(wino_m, **f) if wino_m else None
         b['partial'] = torch.empty(max_partial, **f)
@@ -176,11 +185,12 @@ class Engine:
     def _wino_weights(self, spec):
         w, _ = self._weight(spec)
         key = (w.data_ptr(), w._version, self.m._hip_epoch if not spec.frozen else 0)
+        rows = spec.rows_pad if not spec.is_head else _rup(spec.co_pad, 128)
         if spec.wino_u is None or spec.wino_u.device != w.device:
-            spec.wino_u = torch.empty(16 * spec.rows_pad * spec.cin, device=w.device, dtype=torch.float32)
+            spec.wino_u = torch.empty(16 * rows * spec.cin, device=w.device, dtype=torch.float32)
             spec.wino_key = None
         if spec.wino_key != key:
-            _lib.check(self.lib.ssdhip_winograd_weight(_lib.ptr(w), _lib.ptr(spec.wino_u), spec.cout, spec.cin, spec.rows_pad, spec.cin,
+            _lib.check(self.lib.ssdhip_winograd_weight(_lib.ptr(w), _lib.ptr(spec.wino_u), spec.cout, spec.cin, rows, spec.cin,
                                                        _lib.stream()), 'winograd_weight')
             spec.wino_key = key
         return spec.wino_u
@@ -215,6 +225,26 @@ class Engine:
                                   flops=2.0 * 16 * tp * spec.cin * spec.cout, e0=e0, e1=e1))
         return _lib.check(L.ssdhip_winograd_output(_lib.ptr(Mo), _lib.ptr(bias), _lib.ptr(z), _lib.ptr(stats), N, h, w, spec.cout, st),
                           f'winograd_output {spec.name}')
+
+    def _head_winograd(self, spec, x, xs, V, b, out_ptr, out_batch_stride, N, h, w):
+        """Detector head forward through Winograd; V (input transform of the head's activation) stays valid for backward."""
+        L, st = self.lib, _lib.stream()
+        U = self._wino_weights(spec)
+        _, bias = self._weight(spec)
+        Mo = b['wino_m']
+        tp = (N * ((h + 1) // 2) * ((w + 1) // 2) + 127) // 128 * 128
+        _lib.check(L.ssdhip_winograd_input(_lib.ptr(x), _lib.ptr(xs[0]) if xs is not None else None,
+                                           _lib.ptr(xs[1]) if xs is not None else None, _lib.ptr(V), N, h, w, spec.cin, st), f'winograd_input {spec.name}')
+        cp = spec.co_pad
+        p = _lib.ConvParams()
+        p.x, p.w, p.y, p.y_batch_stride = V.data_ptr(), U.data_ptr(), Mo.data_ptr(), tp * cp
+        p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout = 16, 1, tp, spec.cin, 1, tp, cp
+        p.R, p.S, p.stride, p.pad, p.KP, p.mode, p.accumulate = 1, 1, 1, 0, spec.cin, 0, 0
+        p.tile = 128128 if cp <= 128 else 128064
+        p.rows_per_img, p.w_img_stride = tp, _rup(cp, 128) * spec.cin
+        _lib.check(L.ssdhip_conv2d_nhwc(ctypes.byref(p), st), f'winograd gemm {spec.name}')
+        _lib.check(L.ssdhip_winograd_output_head(_lib.ptr(Mo), _lib.ptr(bias), out_ptr, out_batch_stride, N, h, w, spec.cout, cp, st),
+                   f'winograd_output_head {spec.name}')
 
     def _conv(self, spec, x, xs, y, y_batch_stride, N, hi, wi, ho, wo, stats, tile=0):
         w = self._pack(spec)
@@ -301,8 +331,12 @@ class Engine:
             acts.append((z, act_xs, cur, cur_xs))
             if s.head is not None:
                 off = b['head_off'][s.head_index]
-                self._conv(s.head, z, act_xs, out.data_ptr() + off * self.row * 4, b['P'] * self.row, N, g['ho'], g['wo'],
-                           g['ho'], g['wo'], None)
+                if i in b['head_v']:
+                    self._head_winograd(s.head, z, act_xs, b['head_v'][i], b, ctypes.c_void_p(out.data_ptr() + off * self.row * 4),
+                                        b['P'] * self.row, N, g['ho'], g['wo'])
+                else:
+                    self._conv(s.head, z, act_xs, out.data_ptr() + off * self.row * 4, b['P'] * self.row, N, g['ho'], g['wo'],
+                               g['ho'], g['wo'], None)
         if nbt:
             torch._foreach_add_(nbt, 1)
         self._saved = dict(b=b, N=N, acts=acts, training=training) if save else None
@@ -369,8 +403,9 @@ class Engine:
         p.dy_batch_stride = ho * wo * p.dy_row
         return p
 
-    def _wgrad(self, spec, x, xs, dy, views, bw, N, hi, wi, ho, wo):
+    def _wgrad(self, spec, x, xs, dy, views, bw, N, hi, wi, ho, wo, wino_v=None):
         p = self._wgrad_params(spec, N, hi, wi, ho, wo)
+        p.wino_v = wino_v.data_ptr() if wino_v is not None else None
         prefix = ('detectors.' if spec.is_head else 'features.') + spec.name
         p.x, p.dy = x.data_ptr(), dy.data_ptr()
         p.in_scale = xs[0].data_ptr() if xs is not None else None
@@ -421,7 +456,7 @@ class Engine:
             s, g = self.stages[i], geo[i]
             if s.head is not None:
                 x, xs = acts[i][0], acts[i][1]
-                self._wgrad(s.head, x, xs, bw['dyh'][i], views, bw, N, g['ho'], g['wo'], g['ho'], g['wo'])
+                self._wgrad(s.head, x, xs, bw['dyh'][i], views, bw, N, g['ho'], g['wo'], g['ho'], g['wo'], b['head_v'].get(i))
         last = len(self.stages) - 1
         for i in range(last, self.tail_start - 1, -1):
             s, g = self.stages[i], geo[i]
@@ -429,7 +464,7 @@ class Engine:
             da, dz = bw['da'][i], bw['dz'][i]
             x_act, x_xs = acts[i][0], acts[i][1]        # this stage's activation (input of its head)
             if s.head is not None:
-                self._wgrad(s.head, x_act, x_xs, bw['dyh'][i], views, bw, N, g['ho'], g['wo'], g['ho'], g['wo'])
+                self._wgrad(s.head, x_act, x_xs, bw['dyh'][i], views, bw, N, g['ho'], g['wo'], g['ho'], g['wo'], b['head_v'].get(i))
                 self._dgrad(s.head, bw['dyh'][i], da, N, g['ho'], g['wo'], g['ho'], g['wo'], accumulate=(i != last))
             # BatchNorm(train) + ReLU backward: da -> dz, d gamma, d beta
             bst = self._bn[s.bn_name]

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     # the ctypes mirrors must have the C layout the header declares (8 pointers/int64 then int32s)
     assert ctypes.sizeof(_lib.ConvParams) == 8 * 8 + 16 * 4 + 8
-    assert ctypes.sizeof(_lib.WgradParams) == 8 * 8 + 12 * 4
+    assert ctypes.sizeof(_lib.WgradParams) == 8 * 8 + 12 * 4 + 4 + 4 + 8
 
 
 def test_module_surface_matches_reference_contract():
