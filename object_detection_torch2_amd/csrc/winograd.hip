@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void winograd_input_kernel(const float4* __res
 }
 
 // block = (256 / C4o) tile lanes x C4o channel quads; each block walks TB tiles and emits one row of BN partial sums
-constexpr int WINO_TB = 64;
+constexpr int WINO_TB = 8;     // tiles per block: 19x19 maps at batch 32 have only 3,200 tiles, so small blocks keep all 256 CUs busy
 
 __global__ __launch_bounds__(256) void winograd_output_kernel(const float4* __restrict__ Mo, const float4* __restrict__ bias,
                                                               float4* __restrict__ y, float* __restrict__ stats, int H, int W, int C4o,

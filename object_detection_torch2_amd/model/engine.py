@@ -152,7 +152,8 @@ class Engine:
             b['z'].append(torch.empty(N, g['ho'], g['wo'], s.conv.cout, **f))
             b['pooled'].append(torch.empty(N, g['ha'], g['wa'], s.conv.cout, **f) if s.pool_pad is not None else None)
             M = N * g['ho'] * g['wo']
-            max_partial = max(max_partial, ((M + 63) // 64) * s.conv.cout * 2)   # BM >= 64 for every kernel
+            # BN partial rows: one per 64-row m-tile (direct kernels, BM >= 64) or per 8 Winograd tiles (= 32 pixels)
+            max_partial = max(max_partial, ((M + 31) // 32 + 8) * s.conv.cout * 2)
             cmax = max(cmax, s.conv.cout)
             if s.head is not None:           # heads read the activation BEFORE the pool (ssd.py:100-104 order)
                 offs.append(p)

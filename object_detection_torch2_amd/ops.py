@@ -181,6 +181,6 @@ def conv3x3_winograd(x, w_oihw, bias=None, in_scale=None, in_shift=None, want_st
     p.R, p.S, p.stride, p.pad, p.KP, p.mode, p.accumulate, p.tile = 1, 1, 1, 0, C, 0, 0, tile
     p.rows_per_img, p.w_img_stride = Tp, rows_pad * C
     _lib.check(lib.ssdhip_conv2d_nhwc(ctypes.byref(p), st), 'winograd gemm')
-    stats = torch.empty((T + 63) // 64, cout, 2, device=dev, dtype=torch.float32) if want_stats else None
+    stats = torch.empty((T + 7) // 8, cout, 2, device=dev, dtype=torch.float32) if want_stats else None
     _lib.check(lib.ssdhip_winograd_output(_lib.ptr(Mo), _lib.ptr(bias), _lib.ptr(z), _lib.ptr(stats), N, H, W, cout, st), 'winograd_output')
     return z, stats

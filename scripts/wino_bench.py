@@ -22,7 +22,7 @@ for name, H, cin, cout in L:
     t_, tp_ = ctypes.c_int(), ctypes.c_int(); lib.ssdhip_winograd_tiles(N, H, H, ctypes.byref(t_), ctypes.byref(tp_)); Tn, Tp = t_.value, tp_.value
     rows_pad = (cout + 127) // 128 * 128
     U = torch.empty(16 * rows_pad * cin, device=DEV); V = torch.empty(16 * Tp * cin, device=DEV); Mo = torch.empty(16 * Tp * cout, device=DEV)
-    z = torch.empty(N, H, H, cout, device=DEV); stats = torch.empty((Tn + 63) // 64, cout, 2, device=DEV); st = _lib.stream()
+    z = torch.empty(N, H, H, cout, device=DEV); stats = torch.empty((Tn + 7) // 8, cout, 2, device=DEV); st = _lib.stream()
     lib.ssdhip_winograd_weight(_lib.ptr(w), _lib.ptr(U), cout, cin, rows_pad, cin, st)
     ti = T(lambda: lib.ssdhip_winograd_input(_lib.ptr(x), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(V), N, H, H, cin, st))
     res = {}
