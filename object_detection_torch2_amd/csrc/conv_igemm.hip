@@ -19,6 +19,10 @@
 //   tile order  XCD-aware: each XCD's L2 sees a contiguous run of m-tiles with all their n-tiles
 #include "common.h"
 
+// gemm_planes.hip: LDS-DMA staged plane GEMM (Winograd domain)
+int ssdhip_gemm_planes_dma(const float* v, const float* u, float* y, int M, int K, int Cout, int rows_per_plane, long long u_plane_stride,
+                           int BM, int BN, int tpb, hipStream_t st);
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -391,7 +395,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 int choose_tile(const ssdhip_conv_params* p, int& BM, int& BN) {
-    if (p->tile) { BM = (p->tile / 1000) % 1000; BN = p->tile % 1000; }
+    if (p->tile % 1000000) { BM = (p->tile / 1000) % 1000; BN = p->tile % 1000; }
     else {
         const int64_t M = (int64_t)p->N * p->Ho * p->Wo;
         BN = (p->Cout <= 64 || cdiv(p->Cout, 64) * 64 < cdiv(p->Cout, 128) * 128) ? 64 : 128;
@@ -472,11 +476,20 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
         a.tpb = (int)(tiles / (256 * 6));
         if (a.tpb < 1) a.tpb = 1;
         if (a.tpb > 8) a.tpb = 8;
+        // plain row-major planes: stage with the LDS-DMA engine (gemm_planes.hip) unless tile code 9xxxxxx asks for the
+        // register-staged kernel (A/B comparison in scripts/wino_bench.py)
+        if (p->tile / 1000000 != 9 && !(BM == 64 && BN == 64) && p->KP == p->Cin && p->Cin % BK == 0 && p->Cin >= 256) {   // K = 128: register staging measured faster
+            int rc = ssdhip_gemm_planes_dma(p->x, p->w, p->y, a.M, p->Cin, p->Cout, p->rows_per_img, p->w_img_stride, BM, BN, a.tpb,
+                                            (hipStream_t)stream);
+            if (rc != SSDHIP_OK) { ssdhip_set_error("conv2d: plane GEMM tile not compiled"); return rc; }
+            SSDHIP_CHECK_LAUNCH();
+            return SSDHIP_OK;
+        }
     }
     a.OWf = p->Wo; a.oh0 = 0; a.ow0 = 0; a.ostep = 1; a.r0 = 0; a.s0 = 0; a.rstep = 1; a.nr = p->R; a.ns = p->S;
     hipStream_t st = (hipStream_t)stream;
     const bool xf = p->in_scale != nullptr;
-    if (p->tile >= 1000000) {   // timing-only ablations of the 128x128 3x3 kernel (scripts/conv_bench.py)
+    if (p->tile >= 1000000 && p->tile / 1000000 != 9) {   // timing-only ablations of the 128x128 3x3 kernel (scripts/conv_bench.py)
         SSDHIP_REQUIRE(BM == 128 && BN == 128 && p->R == 3 && p->mode == 0 && p->Cin != 4 && xf, "conv2d: ablation tile");
         dim3 grid(a.MB * a.NB), block(256);
         if (p->tile / 1000000 == 1) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 3, 0, true, false, 1>), grid, block, 0, st, a);

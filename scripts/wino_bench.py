@@ -26,7 +26,7 @@ for name, H, cin, cout in L:
     lib.ssdhip_winograd_weight(_lib.ptr(w), _lib.ptr(U), cout, cin, rows_pad, cin, st)
     ti = T(lambda: lib.ssdhip_winograd_input(_lib.ptr(x), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(V), N, H, H, cin, st))
     res = {}
-    for tile in (128128, 64128, 128064, 64064):
+    for tile in (128128, 64128, 128064, 9128128, 9064128):
         p = _lib.ConvParams(); p.x, p.w, p.y, p.y_batch_stride = V.data_ptr(), U.data_ptr(), Mo.data_ptr(), Tp * cout
         p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout = 16, 1, Tp, cin, 1, Tp, cout
         p.R, p.S, p.stride, p.pad, p.KP, p.mode, p.accumulate, p.tile = 1, 1, 1, 0, cin, 0, 0, tile
