@@ -43,7 +43,9 @@ class FusedAdam(torch.optim.Optimizer):
                     blockmap=torch.tensor(blocks, dtype=torch.int32, device=dev),
                     hyper=old['hyper'] if old else torch.tensor([group['lr'], b1, b2, group['eps'], group['weight_decay'], 1.0, 1.0,
                                                                  group['grad_scale']], dtype=torch.float32, device=dev),
-                    step=old['step'] if old else torch.zeros(1, dtype=torch.int32, device=dev),
+                    # device step counter; resumes from the checkpointed per-parameter step (load_state_dict), like torch.optim.Adam
+                    step=old['step'] if old else torch.full((1,), int(max(int(self.state[p].get('step', 0)) for p in params)),
+                                                            dtype=torch.int32, device=dev),
                     host=old['host'] if old else (group['lr'], group['weight_decay'], group['grad_scale']))
         self._plans[gi] = plan
         return plan

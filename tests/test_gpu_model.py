@@ -169,3 +169,59 @@ def test_inference_and_evaluation_path(env):
             assert r.shape[1] == 2 and set(r[:, 0].unique().tolist()) <= {0.0, 1.0}
             ap = E.calc_average_precision(r, max(count[c], 1), True).item()
             assert 0.0 <= ap <= 1.0 + 1e-6
+
+
+def test_forward_full_batch_properties(env):
+    """Size-independent properties at the headline size (N = 32): bit-reproducible replay (no atomics anywhere on the path,
+    LDS races would show as differing bits) and batch-permutation equivariance (train-mode BN statistics are permutation
+    invariant up to summation order)."""
+    synth = env['synth']
+    net = make_net(env)
+    x = torch.from_numpy(synth.images(70, 32)).to(DEV)
+    with torch.no_grad():
+        y1 = net(x)
+        y2 = net(x)
+        assert torch.equal(y1, y2)
+        perm = torch.randperm(32, generator=torch.Generator().manual_seed(3)).to(DEV)
+        yp = net(x[perm].contiguous())
+    assert y1.shape == (32, 8732, 25) and torch.isfinite(y1).all()
+    assert (yp - y1[perm]).abs().max().item() < 2e-3
+
+
+def test_fused_adam_checkpoint_resume(env):
+    """Optimizer state round-trip (the reference does not checkpoint Adam): state_dict -> new optimizer ->
+    identical next step, including the bias-correction step count kept on the device."""
+    from object_detection_torch2_amd.optim import FusedAdam
+    synth = env['synth']
+    df = None
+    nets, opts = [], []
+    for _ in range(2):
+        net = make_net(env)
+        nets.append(net)
+        opts.append(FusedAdam(net.train_params(), lr=1e-3, weight_decay=5e-4, on_step=net.hip_weights_changed))
+    df = nets[0].default_bboxes.to(DEV)
+    ims = torch.from_numpy(synth.images(80, 2)).to(DEV)
+    tgs = torch.from_numpy(synth.targets(81, 2)).to(DEV)
+
+    def step(net, opt):
+        opt.zero_grad()
+        loss = net.loss(net(ims), tgs, df)
+        loss.backward()
+        opt.step()
+        return loss.item()
+
+    for _ in range(2):
+        step(nets[0], opts[0])
+    # resume: weights + BN buffers + optimizer state through a serialized checkpoint (torch's Optimizer.load_state_dict
+    # does not copy tensors that already have the right dtype/device, so an in-memory hand-over would share exp_avg)
+    import io
+    buf = io.BytesIO()
+    torch.save({'net': nets[0].state_dict(), 'opt': opts[0].state_dict()}, buf)
+    buf.seek(0)
+    ckpt = torch.load(buf, map_location=DEV, weights_only=True)
+    nets[1].load_state_dict(ckpt['net'])
+    opts[1].load_state_dict(ckpt['opt'])
+    l0, l1 = step(nets[0], opts[0]), step(nets[1], opts[1])
+    assert l0 == l1
+    for (k, a), (_, b) in zip(nets[0].state_dict().items(), nets[1].state_dict().items()):
+        assert torch.equal(a, b), k
