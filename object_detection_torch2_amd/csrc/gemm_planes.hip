@@ -9,6 +9,10 @@
 //                                     no VALU: per K-step a wave issues (BM + BN) / 32 DMA instructions and 16*MT*NT MFMAs.
 //   one-ahead double buffer           K-step g: DMA of step g+1 into the other buffer (its readers passed the previous barrier),
 //                                     MFMAs on buffer g & 1, then s_waitcnt vmcnt(0) + s_barrier: a full K-step of latency cover
+//                                     (fragment ds_reads are asm with explicit lgkmcnt waits, see the loop)
+//   measured (scripts/plane_gemm_probe.py, conv_4_2 planes): 122-126 TF; without the DMA stream 133-137 TF, without the
+//   epilogue stores 130 TF; dropping the vmcnt wait or the barrier changes nothing (not latency-bound); grid quantisation
+//   (5,824 tiles over 512 resident slots) costs 5 %
 //   persistent blocks                 a block walks `tpb` consecutive m-tiles of one n-tile as one pipeline (K = Cin is short:
 //                                     4..32 K-steps), storing each finished tile from inside the loop
 //   tile order                        XCD-aware, n-tiles of an m-chunk adjacent (V rows are read once per n-tile from L2)
@@ -17,6 +21,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 constexpr int BK = 32, LROW = 32;
@@ -32,7 +37,7 @@ struct PlaneArgs {
 template <int BM, int BN>
 struct PlaneWaves { static constexpr int value = (BM + BN == 256) ? 2 : 3; };
 
-template <int BM, int BN>
+template <int BM, int BN, int ABL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, PlaneWaves<BM, BN>::value))) void gemm_planes_dma_kernel(PlaneArgs a) {
     constexpr int WROWS = BM / 2, WCOLS = BN / 2, MT = WROWS / 32, NT = WCOLS / 32, AL = BM / 32, BL = BN / 32;
     __shared__ __attribute__((aligned(1024))) float lds[2 * (BM + BN) * LROW];
@@ -96,43 +101,58 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, PlaneWav
     issue(0);
     __syncthreads();                       // emits s_waitcnt vmcnt(0): step 0 has landed for every wave
 
+    // Fragment reads are written as asm: the compiler cannot tell an LDS-DMA write into the OTHER buffer from the ds_reads of
+    // this one and would put s_waitcnt vmcnt(0) in front of the first ds_read after the DMA issue (one quarter of a K-step of
+    // latency cover instead of a whole one).  Waits are explicit; the "+v" operands tie each wait to the registers it covers.
     const int frow = lane & 31, fh = lane >> 5, fx = (frow >> 1) & 7;
-    int fko[4];
+    unsigned fko[4];
 #pragma unroll
-    for (int kc = 0; kc < 4; ++kc) fko[kc] = ((2 * kc + fh) ^ fx) * 4;
-    const float* Afr = As + (wm * WROWS + frow) * LROW;
-    const float* Bfr = Bs + (wn * WCOLS + frow) * LROW;
+    for (int kc = 0; kc < 4; ++kc) fko[kc] = (unsigned)(((2 * kc + fh) ^ fx) * 16);
+    const unsigned a_lds = (unsigned)(uintptr_t)(lptr_t)(As + (wm * WROWS + frow) * LROW);
+    const unsigned b_lds = (unsigned)(uintptr_t)(lptr_t)(Bs + (wn * WCOLS + frow) * LROW);
     const int total = ntl * a.KT;
     int kt_in = 0, m_cur = m0;
     for (int g = 0; g < total; ++g) {
         const int buf = g & 1;
-        const float* Ab = Afr + buf * BM * LROW;
-        const float* Bb = Bfr + buf * BN * LROW;
-        float4 fa[2][MT], fb[2][NT];
+        const unsigned ab = a_lds + (unsigned)(buf * BM * LROW * 4), bb = b_lds + (unsigned)(buf * BN * LROW * 4);
+        f32x4 fa[2][MT], fb[2][NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) fa[0][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LROW + fko[0]);
+        for (int i = 0; i < MT; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[0][i]) : "v"(ab + fko[0]), "n"(i * 32 * LROW * 4));
 #pragma unroll
-        for (int j = 0; j < NT; ++j) fb[0][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LROW + fko[0]);
-        issue(buf ^ 1);                    // next K-step streams into the other buffer while this one is consumed
+        for (int j = 0; j < NT; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[0][j]) : "v"(bb + fko[0]), "n"(j * 32 * LROW * 4));
+        if (ABL != 2) issue(buf ^ 1);                    // next K-step streams into the other buffer while this one is consumed
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
             const int cur = kc & 1;
             if (kc < 3) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i) fa[cur ^ 1][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LROW + fko[kc < 3 ? kc + 1 : 0]);
+                for (int i = 0; i < MT; ++i)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[cur ^ 1][i]) : "v"(ab + fko[kc < 3 ? kc + 1 : 0]), "n"(i * 32 * LROW * 4));
 #pragma unroll
-                for (int j = 0; j < NT; ++j) fb[cur ^ 1][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LROW + fko[kc < 3 ? kc + 1 : 0]);
+                for (int j = 0; j < NT; ++j)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[cur ^ 1][j]) : "v"(bb + fko[kc < 3 ? kc + 1 : 0]), "n"(j * 32 * LROW * 4));
             }
+            // the fragments of `cur` were issued one kc earlier: everything but the (MT + NT) reads just issued has landed
+            if constexpr (MT == 2 && NT == 2) {
+                if (kc < 3) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[cur][0]), "+v"(fa[cur][1]), "+v"(fb[cur][0]), "+v"(fb[cur][1]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[cur][0]), "+v"(fa[cur][1]), "+v"(fb[cur][0]), "+v"(fb[cur][1]));
+            } else if constexpr (MT == 2) {
+                if (kc < 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa[cur][0]), "+v"(fa[cur][1]), "+v"(fb[cur][0]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[cur][0]), "+v"(fa[cur][1]), "+v"(fb[cur][0]));
+            } else {
+                if (kc < 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa[cur][0]), "+v"(fb[cur][0]), "+v"(fb[cur][1]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[cur][0]), "+v"(fb[cur][0]), "+v"(fb[cur][1]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int el = 0; el < 4; ++el)
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
-                        const float av = el == 0 ? fa[cur][i].x : el == 1 ? fa[cur][i].y : el == 2 ? fa[cur][i].z : fa[cur][i].w;
-                        const float bv = el == 0 ? fb[cur][j].x : el == 1 ? fb[cur][j].y : el == 2 ? fb[cur][j].z : fb[cur][j].w;
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][el], fb[cur][j][el], acc[i][j], 0, 0, 0);
                     }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (++kt_in == a.KT) {             // tile finished: dense rows of M, then restart the accumulators
             kt_in = 0;
@@ -144,13 +164,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, PlaneWav
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int m = m_cur + wm * WROWS + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                        if (co < a.Cout) a.y[(size_t)m * a.Cout + co] = acc[i][j][e];
+                        if (co < a.Cout && (ABL != 1 || acc[i][j][e] == 123.456f)) a.y[(size_t)m * a.Cout + co] = acc[i][j][e];
                         acc[i][j][e] = 0.f;
                     }
             }
             m_cur += BM;
         }
-        __syncthreads();                   // vmcnt(0) + barrier: the other buffer is complete and this one is free
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next K-step has landed ...
+        __builtin_amdgcn_s_barrier();                      // ... and so has everyone else's; this buffer is free again
     }
 }
 
@@ -158,13 +179,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, PlaneWav
 
 // called from ssdhip_conv2d_nhwc (conv_igemm.hip) for plane GEMMs
 int ssdhip_gemm_planes_dma(const float* v, const float* u, float* y, int M, int K, int Cout, int rows_per_plane, long long u_plane_stride,
-                           int BM, int BN, int tpb, hipStream_t st) {
+                           int BM, int BN, int tpb, hipStream_t st, int abl) {
     PlaneArgs a;
     a.v = v; a.u = u; a.y = y; a.u_plane_stride = u_plane_stride;
     a.M = M; a.K = K; a.KT = K / BK; a.Cout = Cout; a.rows_per_plane = rows_per_plane;
     a.MB = M / BM; a.NB = cdiv(Cout, BN); a.tpb = tpb;
     dim3 grid(cdiv(a.MB, a.tpb) * a.NB), block(256);
-    if (BM == 128 && BN == 128) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128>), grid, block, 0, st, a);
+    if (abl == 1) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128, 1>), grid, block, 0, st, a);
+    else if (abl == 2) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128, 2>), grid, block, 0, st, a);
+    else if (BM == 128 && BN == 128) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128>), grid, block, 0, st, a);
     else if (BM == 128 && BN == 64) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 64>), grid, block, 0, st, a);
     else if (BM == 64 && BN == 128) hipLaunchKernelGGL((gemm_planes_dma_kernel<64, 128>), grid, block, 0, st, a);
     else return SSDHIP_ENOSUP;

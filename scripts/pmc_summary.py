@@ -11,7 +11,8 @@ for tag in ('fetch', 'write', 'sq'):
     if not files:
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(files[0])):
+    files.sort(key=os.path.getmtime)           # merged scratch dirs keep older passes: take the newest
+    for r in csv.DictReader(open(files[-1])):
         agg[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
     for k, cs in agg.items():
         for c, v in cs.items():
