@@ -190,6 +190,16 @@ int ssdhip_adam_multi_tensor(const void* const* table, const int64_t* sizes, con
  * adam_tick increments the device step counter and refreshes slots 5,6 (graph-replayable step bookkeeping).  */
 int ssdhip_adam_tick(int32_t* step, float* hyper, void* stream);
 
+/* ---- 8(f)-2  batch augmentation (augmentation/random.py:6-42, augmentation/to_tensor.py:8-16, applied per sample at
+ * dataset.py:43-52; pipeline train.py:32-36): colour jitter ops in the sampled order, horizontal flip, uint8 -> [0,1]
+ * fp32 (ToTensor) and up to three erased boxes, on the whole batch.
+ * src: (N,H,W,3) uint8 as decoded + resized by the dataset; params: (N, ssdhip_augment_row_floats()) fp32 rows
+ * [n_colour_ops (0|4), op order x4 (0 brightness 1 contrast 2 saturation 3 hue), factor of op 0..3, flip, n_erase (<=3),
+ *  3 x (top,left,height,width)]; out: (N,3,H,W) fp32; ws: ssdhip_augment_ws_bytes(N) bytes.                              */
+int ssdhip_augment_row_floats(void);
+int64_t ssdhip_augment_ws_bytes(int N);
+int ssdhip_augment_batch(const uint8_t* src_nhwc_u8, const float* params, int N, int H, int W, float* out_nchw, void* ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,9 @@ SIGNATURES = {
     'ssdhip_scatter_head_grad': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ssdhip_adam_multi_tensor': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'ssdhip_adam_tick': (c_int, [c_void_p, c_void_p, c_void_p]),
+    'ssdhip_augment_row_floats': (c_int, []),
+    'ssdhip_augment_ws_bytes': (c_int64, [c_int]),
+    'ssdhip_augment_batch': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -84,7 +84,9 @@ def main():
     parser.add_argument('--num_workers', type=int, default=8)
     parser.add_argument('--result_dir', type=str, default='./result')
     parser.add_argument('--weights', type=str, default='weights.pth')
-    parser.add_argument('--batches', type=int, default=2)
+    parser.add_argument('--batches', type=int, default=2, help='synthetic source only')
+    parser.add_argument('--data_dirs', type=str, nargs='*', default=None, help='VOC roots (evaluate.py:96: VOC2007 test)')
+    parser.add_argument('--data_list', type=str, default='test.txt')
     args = parser.parse_args()
 
     out_dir = Path(args.result_dir) / 'detection'
@@ -97,6 +99,14 @@ def main():
     labelmap = LabelMap('PascalVOC')
 
     def batches():
+        if args.data_dirs:                                # evaluate.py:91-102: ToTensor only, batches through collate_fn
+            from . import augmentation as aug
+            from .dataset import PascalVOCDataset
+            from .utils import collate_fn
+            data = PascalVOCDataset('detection', args.data_dirs, args.data_list, args.imsize, transform=aug.Compose([aug.ToTensor()]))
+            for images, gts in torch.utils.data.DataLoader(data, batch_size=args.batch_size, num_workers=args.num_workers, collate_fn=collate_fn):
+                yield images.to(device), gts.to(device)
+            return
         for b in range(args.batches):
             yield (torch.from_numpy(synth.images(3000 + b, args.batch_size, args.imsize)).to(device),
                    torch.from_numpy(synth.targets(4000 + b, args.batch_size)).to(device))

@@ -4,10 +4,12 @@
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m object_detection_torch2_amd.train ...
 
 The loop body is the reference's (train.py:103-125): zero_grad -> forward -> loss -> backward -> step, ExponentialLR per
-epoch, weights.pth / params.json when the epoch loss improves.  Differences, all deliberate: data are synthetic batches
-(the Pascal-VOC loader and torchvision augmentations are outside this path and not installed here; --synthetic is the
-only source), torch.autograd.set_detect_anomaly is off, the optimizer is the fused HIP Adam, and under torchrun each
-rank takes a contiguous shard of the global batch and gradients are all-reduced with RCCL.
+epoch, weights.pth / params.json when the epoch loss improves.  Data: synthetic batches by default (no dataset ships with
+this image); with --data_dirs the reference's pipeline (train.py:32-66) on the drop-in `dataset` / `augmentation` modules:
+PIL decode + resize in DataLoader workers, colour jitter / flip / erasing in one device pass per batch.  Other deliberate
+differences: torch.autograd.set_detect_anomaly is off, the optimizer is the fused HIP Adam, and under torchrun each rank
+takes a contiguous shard of the global batch (synthetic) or a DistributedSampler shard (VOC) and gradients are
+all-reduced with RCCL.
 """
 import argparse
 import json
@@ -16,7 +18,9 @@ from pathlib import Path
 
 import torch
 
-from . import parallel, synth
+from . import augmentation as aug, parallel, synth
+from .dataset import PascalVOCDataset
+from .utils import collate_fn
 from .model import SSD
 from .optim import FusedAdam
 
@@ -35,7 +39,9 @@ def main():
     parser.add_argument('--weights', type=str, default='weights.pth')
     parser.add_argument('--params', type=str, default='params.json')
     parser.add_argument('--synthetic', action='store_true', default=True, help='synthetic 300x300x3 batches (only data source here)')
-    parser.add_argument('--steps_per_epoch', type=int, default=20)
+    parser.add_argument('--steps_per_epoch', type=int, default=20, help='synthetic source only')
+    parser.add_argument('--data_dirs', type=str, nargs='*', default=None, help='VOC roots, e.g. /work/data/VOCdevkit/VOC2007 (train.py:43)')
+    parser.add_argument('--data_list', type=str, default='trainval.txt')
     args = parser.parse_args()
     if args.purpose != 'detection':
         raise SystemExit('only --purpose detection is on the MI355X path (VGG16 classification pre-training is out of scope)')
@@ -65,24 +71,44 @@ def main():
     scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=args.gamma)
     lo, hi = parallel.shard_batch(args.batch_size * world, rank, world)      # --batch_size is per GPU
 
+    loader = sampler = None
+    if args.data_dirs:
+        pipeline = aug.Compose([aug.RandomColorJitter(p=0.5), aug.RandomFlip(p=0.5), aug.ToTensor(), aug.RandomErasing(p=0.5, max_iter=3)])
+        data = PascalVOCDataset(purpose=args.purpose, data_dirs=args.data_dirs, data_list_file_name=args.data_list, imsize=args.imsize,
+                                transform=pipeline)
+        sampler = torch.utils.data.distributed.DistributedSampler(data, world, rank, shuffle=True) if world > 1 else None
+        loader = torch.utils.data.DataLoader(data, batch_size=args.batch_size, shuffle=sampler is None, sampler=sampler,
+                                             num_workers=args.num_workers, collate_fn=collate_fn, drop_last=world > 1)
+
+    def batches(epoch):
+        if loader is not None:
+            if sampler is not None:
+                sampler.set_epoch(epoch)
+            for images, gts in loader:
+                yield images.to(device), gts.to(device)          # DeferredBatch.to = upload uint8 + device augmentation pass
+            return
+        for i in range(args.steps_per_epoch):
+            seed = epoch * 100003 + i
+            yield (torch.from_numpy(synth.images(seed, args.batch_size * world, args.imsize)[lo:hi]).to(device),
+                   torch.from_numpy(synth.targets(seed, args.batch_size * world)[lo:hi]).to(device))
+
     for epoch in range(1 + start_epoch, args.epochs + start_epoch + 1):
         running = torch.zeros((), device=device)
         t0 = time.perf_counter()
-        for i in range(args.steps_per_epoch):
-            seed = epoch * 100003 + i
-            ims = torch.from_numpy(synth.images(seed, args.batch_size * world, args.imsize)[lo:hi]).to(device)
-            gts = torch.from_numpy(synth.targets(seed, args.batch_size * world)[lo:hi]).to(device)
+        n_steps = 0
+        for ims, gts in batches(epoch):
+            n_steps += 1
             optimizer.zero_grad()
             outputs = net(ims)
             loss = net.loss(outputs=outputs, targets=gts, default_bboxes=defaults)
             loss.backward()
             optimizer.step()
             running += loss.detach()
-        running_loss = running.item() / args.steps_per_epoch
+        running_loss = running.item() / max(n_steps, 1)
         dt = time.perf_counter() - t0
         if rank == 0:
             print(f'[Epoch {epoch}/{args.epochs + start_epoch}] loss: {round(running_loss, 5)} lr: {scheduler.get_last_lr()[0]:.6f} '
-                  f'({args.steps_per_epoch * args.batch_size * world / dt:.1f} img/s incl. synthetic data generation)')
+                  f'({n_steps * args.batch_size * world / dt:.1f} img/s incl. data loading)')
             if (min_loss is None) or (running_loss < min_loss):
                 parallel.sync_bn_stats(net) if world > 1 else None
                 weights_path.parent.mkdir(parents=True, exist_ok=True)

@@ -10,8 +10,14 @@ from . import _lib
 
 
 def collate_fn(batch):
-    """utils.py:8-16: stack images, zero-pad GT rows to Gmax (host-side data contract, no kernel involved)."""
-    images = torch.stack([im for im, _ in batch], dim=0)
+    """utils.py:8-16: stack images, zero-pad GT rows to Gmax (host-side data contract, no kernel involved).  Images that
+    come out of the augmentation pipeline as `Deferred` (uint8 + pending device work) are stacked into a `DeferredBatch`,
+    whose `.to(device)` yields the augmented fp32 batch."""
+    from .augmentation import Deferred, DeferredBatch
+    if isinstance(batch[0][0], Deferred):
+        images = DeferredBatch.stack([im for im, _ in batch])
+    else:
+        images = torch.stack([im for im, _ in batch], dim=0)
     gts = pad_sequence([gt for _, gt in batch], batch_first=True)
     return images, gts
 

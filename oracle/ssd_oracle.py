@@ -367,3 +367,75 @@ def train_step(sd, opt_state, images, targets_np, df, lr=1e-3, wd=5e-4, num_clas
             st = opt_state.setdefault(k, dict(m=np.zeros(sd[k].shape, f32), v=np.zeros(sd[k].shape, f32)))
             adam_step(sd[k].numpy(), sd[k].grad.numpy(), st['m'], st['v'], opt_state['step'], lr=lr, wd=wd)
     return float(lval)
+
+
+# ----------------------------------------------------------------------------
+# batch augmentation (src/augmentation/random.py:6-42 -> torchvision's tensor-path definitions; "parity unpinned":
+# torchvision is not importable here, the formulas below are its published ones: _blend, rgb_to_grayscale,
+# adjust_{brightness,contrast,saturation,hue}, _rgb2hsv/_hsv2rgb, erase with value 0)
+# ----------------------------------------------------------------------------
+def _blend(a, b, f):
+    f = f32(f)
+    return np.clip(f * a + (f32(1) - f) * b, f32(0), f32(1)).astype(f32)
+
+
+def _gray(x):          # x: (H,W,3) fp32
+    return (f32(0.2989) * x[..., 0] + f32(0.587) * x[..., 1] + f32(0.114) * x[..., 2]).astype(f32)
+
+
+def _hue(x, hf):
+    r, g, b = x[..., 0], x[..., 1], x[..., 2]
+    maxc, minc = np.maximum(r, np.maximum(g, b)), np.minimum(r, np.minimum(g, b))
+    eq = maxc == minc
+    cr = maxc - minc
+    s = cr / np.where(eq, f32(1), maxc)
+    div = np.where(eq, f32(1), cr)
+    rc, gc, bc = (maxc - r) / div, (maxc - g) / div, (maxc - b) / div
+    h = np.where(maxc == r, bc - gc, np.where(maxc == g, f32(2) + rc - bc, f32(4) + gc - rc)).astype(f32)
+    h = np.fmod(h / f32(6) + f32(1), f32(1)).astype(f32)
+    h = (h + f32(hf)).astype(f32)
+    h = (h - np.floor(h)).astype(f32)
+    v = maxc
+    h6 = (h * f32(6)).astype(f32)
+    fl = np.floor(h6)
+    f = (h6 - fl).astype(f32)
+    i = fl.astype(np.int32) % 6
+    one = f32(1)
+    p = np.clip(v * (one - s), 0, 1).astype(f32)
+    q = np.clip(v * (one - s * f), 0, 1).astype(f32)
+    t = np.clip(v * (one - s * (one - f)), 0, 1).astype(f32)
+    table = [(v, t, p), (q, v, p), (p, v, t), (p, q, v), (t, p, v), (v, p, q)]
+    out = np.zeros_like(x)
+    for k, (a_, b_, c_) in enumerate(table):
+        m = i == k
+        out[..., 0][m], out[..., 1][m], out[..., 2][m] = a_[m], b_[m], c_[m]
+    return out
+
+
+def augment_batch(u8, rows):
+    """u8 (N,H,W,3) uint8, rows (N,24) fp32 (layout: csrc/augment.hip header) -> (N,3,H,W) fp32."""
+    N, H, W, _ = u8.shape
+    out = np.zeros((N, 3, H, W), dtype=f32)
+    for n in range(N):
+        x = (u8[n].astype(f32) / f32(255)).astype(f32)
+        row = rows[n]
+        for k in range(int(row[0])):
+            op = int(row[1 + k])
+            fac = row[5 + op]
+            if op == 0:
+                x = _blend(x, f32(0), fac)
+            elif op == 1:
+                mean = f32(_gray(x).astype(np.float64).mean())
+                x = _blend(x, mean, fac)
+            elif op == 2:
+                x = _blend(x, _gray(x)[..., None], fac)
+            else:
+                x = _hue(x, fac)
+        if row[9] != 0:
+            x = x[:, ::-1]
+        x = np.array(x, dtype=f32)
+        for k in range(int(row[10])):
+            top, left, h, w = (int(v) for v in row[11 + 4 * k: 15 + 4 * k])
+            x[top:top + h, left:left + w] = 0
+        out[n] = x.transpose(2, 0, 1)
+    return out

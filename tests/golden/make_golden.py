@@ -303,8 +303,48 @@ def gen_eval():
     print('G10 evaluation fixtures ok')
 
 
+def gen_data():
+    """G11: the reference's dataset.PascalVOCDataset (dataset.py:12-116) and utils.collate_fn (utils.py:8-16) on the tiny
+    synthetic VOC tree of tests/voc_fixture.py: ground-truth rows, resized pixels, padded batch."""
+    import tempfile
+    import dataset as ref_ds  # noqa: E402  (reference; imports only utils, PIL, torch)
+    sys.path.insert(0, str(ROOT / 'tests'))
+    import voc_fixture
+    from object_detection_torch2_amd import dataset as my_ds, utils as my_utils
+    fx = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        root = voc_fixture.make_tree(pathlib.Path(tmp))
+        ref = ref_ds.PascalVOCDataset('detection', [str(root)], 'trainval.txt', 300)
+        mine = my_ds.PascalVOCDataset('detection', [str(root)], 'trainval.txt', 300)
+        assert len(ref) == len(mine) == len(voc_fixture.ITEMS)
+        gts = []
+        for i in range(len(ref)):
+            (im_r, gt_r), (im_m, gt_m) = ref[i], mine[i]
+            assert torch.equal(gt_r, gt_m), i
+            assert np.array_equal(np.asarray(im_r), np.asarray(im_m)), i
+            fx[f'gt_{i}'] = gt_r.numpy()
+            fx[f'px_sum_{i}'] = np.asarray(im_r, dtype=np.int64).sum(axis=(0, 1))
+            gts.append(gt_r)
+        batch = [(torch.full((3, 4, 4), float(i)), g) for i, g in enumerate(gts)]
+        ims_r, pad_r = ref_utils.collate_fn(batch)
+        ims_m, pad_m = my_utils.collate_fn(batch)
+        assert torch.equal(ims_r, ims_m) and torch.equal(pad_r, pad_m)
+        fx['padded'] = pad_r.numpy()
+        # purpose='classification' cannot be compared: the reference builds its list before it sets self.labelmap
+        # (dataset.py:29-30 vs :83) and raises AttributeError; recorded so the behaviour is pinned as a known quirk
+        try:
+            ref_ds.PascalVOCDataset('classification', str(root), 'trainval.txt', 224)
+            fx['ref_classification_raises'] = np.int64(0)
+        except AttributeError:
+            fx['ref_classification_raises'] = np.int64(1)
+    np.savez_compressed(OUT / 'g11_data.npz', **fx)
+    print('G11 data-path fixtures ok')
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['post', 'fwd', 'eval']
+    which = sys.argv[1:] or ['post', 'fwd', 'eval', 'data']
+    if 'data' in which:
+        gen_data()
     if 'eval' in which:
         gen_eval()
     if 'post' in which:
