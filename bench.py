@@ -56,6 +56,25 @@ def cpu_baseline(batch=8, steps=2):
                 sample=f'{steps} train steps at batch {batch} (1 warm-up), torch {torch.__version__} CPU ops, {cores} threads')
 
 
+def step_gflop(eng, imsize):
+    """Direct-convolution GFLOP per image (forward, frozen-backbone train step) from the engine's layer table, the way
+    SURVEY.md 8(d) counts them: 2*Ho*Wo*Cout*Cin*k^2 per conv; + wgrad of every trainable conv; + dgrad of every trainable
+    conv whose input carries a gradient (not the first trainable conv, not the head on the frozen conv_4_3)."""
+    fwd = wgrad = dgrad = 0.0
+    geo = eng._geometry(imsize, imsize)
+    for i, (s, g) in enumerate(zip(eng.stages, geo)):
+        f = 2.0 * g['ho'] * g['wo'] * s.conv.cout * s.conv.cin * s.conv.k ** 2
+        fwd += f
+        if not s.conv.frozen:
+            wgrad += f
+            dgrad += f if i > eng.tail_start else 0.0
+        if s.head is not None:
+            fh = 2.0 * g['ho'] * g['wo'] * s.head.cout * s.head.cin * 9
+            fwd += fh; wgrad += fh
+            dgrad += fh if i >= eng.tail_start else 0.0
+    return fwd / 1e9, (fwd + wgrad + dgrad) / 1e9
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -64,6 +83,8 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--imsize', type=int, choices=[300, 512], default=300,
+                    help='300 = the reference network (headline); 512 = SSD512 extension (BASELINE configs[4] is its bf16 8-GPU form; run with --batch 16)')
     ap.add_argument('--mode', choices=['train', 'infer'], default='train',
                     help='train (headline, BASELINE configs[2]) or infer (configs[1]: forward + decode + score + NMS)')
     args = ap.parse_args()
@@ -80,12 +101,12 @@ def main():
     torch.cuda.set_device(dev)
 
     torch.manual_seed(1)
-    net = SSD(num_classes=21).to(dev)               # random-init weights (no pretrained weights offline)
+    net = SSD(num_classes=21, imsize=args.imsize).to(dev)   # random-init weights (no pretrained weights offline)
     df = net.default_bboxes.to(dev)
     world_n = parallel.attach(net) if world > 1 else 1
     opt = FusedAdam(net.train_params(), lr=1e-3, weight_decay=5e-4, grad_scale=1.0 / world_n, on_step=net.hip_weights_changed)
     B = args.batch
-    ims = torch.from_numpy(synth.images(100 + rank, B)).to(dev)       # this rank's shard of the global batch
+    ims = torch.from_numpy(synth.images(100 + rank, B, args.imsize)).to(dev)       # this rank's shard of the global batch
     tgs = torch.from_numpy(synth.targets(200 + rank, B, g_max=8)).to(dev)
     running = torch.zeros((), device=dev)
 
@@ -156,6 +177,9 @@ def main():
                     all_conv_fwd_tflops=round(sum(v['flops'] for v in agg.values()) / (sum(v['ms'] for v in agg.values()) * 1e-3) / 1e12, 2))
     eng.prof = None
 
+    gf_train, gf_fwd = GFLOP_PER_IMAGE_TRAIN, 62.747
+    if args.imsize != 300:
+        gf_fwd, gf_train = step_gflop(eng, args.imsize)
     if rank == 0:
         value = world * B * args.steps / dt
         metric = 'images/sec SSD300 train step, batch 32/GPU' if args.mode == 'train' else \
@@ -167,14 +191,19 @@ def main():
                                          '(BASELINE configs[2]' + ('; data-parallel, RCCL grad all-reduce)' if world > 1 else ')'),
                                 global_batch=world * B, image='300x300x3', priors=8732, classes=21, parallelism=f'dp{world}',
                                 bn='train-mode batch statistics (reference never calls eval())', backbone='frozen VGG16-bn'),
-                    conv_flop_roofline_frac=round(value / world * (GFLOP_PER_IMAGE_TRAIN if args.mode == 'train' else 62.747)
+                    conv_flop_roofline_frac=round(value / world * (gf_train if args.mode == 'train' else gf_fwd)
                                                   / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
                     mean_loss=round(final_loss, 4))
         if roof is not None:
             line['roofline'] = roof
-        if args.mode == 'infer':
+        if args.imsize != 300:      # extension variant, never the headline: say so in every field a reader may look at
+            P = net.topo.num_priors()
+            line['metric'] = f'images/sec SSD{args.imsize} {"train step" if args.mode == "train" else "inference"}, batch {B}/GPU (extension variant, not the BASELINE metric)'
+            line['config'].update(workload=f'SSD{args.imsize} {args.mode} batch={B}/GPU, fp32 ({P} priors; BASELINE configs[4] names its bf16 8-GPU form)',
+                                  image=f'{args.imsize}x{args.imsize}x3', priors=P, gflop_per_image=round(gf_train if args.mode == 'train' else gf_fwd, 3))
+        elif args.mode == 'infer':
             line['config']['workload'] = 'SSD300 inference batch=32, fp32, NMS on 8732 priors x 20 classes (BASELINE configs[1])'
-        if world == 1 and not args.no_cpu_baseline and args.mode == 'train':
+        if world == 1 and not args.no_cpu_baseline and args.mode == 'train' and args.imsize == 300:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:

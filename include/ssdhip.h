@@ -136,10 +136,11 @@ int ssdhip_decode_score(float* outputs, const float* dboxes, int N, int P, int C
 int ssdhip_calc_iou(const float* t, const float* s, int N, int T, int S, int rowt, int rows, float* iou, void* stream);
 /* ---- A22  utils.non_maximum_suppression (utils.py:80-116): greedy, class-agnostic, strict '>' -------------
  * outputs (N,P,4+C) decoded+scored; zeroes outputs[n,p,4:] of suppressed / void rows in place.
- * keep (N,P) uint8 (optional, may be NULL).  P <= 16384.                                                    */
+ * keep (N,P) uint8 (optional, may be NULL).  P <= 9000 (all-LDS).                                                   */
 int ssdhip_nms(float* outputs, int N, int P, int C, float iou_thresh, uint8_t* keep, void* stream);
 /* same result with a caller workspace (ssdhip_nms_ws_bytes): sort per image, IoU bit-matrix over the whole chip, serial
- * scan per image on register-resident suppression bits.  P <= 9984.  Preferred for batches (the LDS-only variant keeps one
+ * scan per image on register-resident suppression bits (P <= 9984), or, for 9984 < P <= 32768 (SSD512 extension), a chunked
+ * sort and a scan over global mask rows.  Preferred for batches (the LDS-only variant keeps one
  * CU per image busy).                                                                                        */
 int64_t ssdhip_nms_ws_bytes(int N, int P);
 int ssdhip_nms_ws(float* outputs, int N, int P, int C, float iou_thresh, uint8_t* keep, void* ws, void* stream);

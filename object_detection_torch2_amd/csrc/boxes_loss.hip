@@ -201,14 +201,16 @@ __device__ unsigned radix_select_desc(const unsigned* __restrict__ vals, int P, 
     return prefix;
 }
 
+// `single` (P too large for two staged rows, e.g. SSD512's 24,564 priors): one LDS row, staged twice (positives, then negatives)
 __global__ __launch_bounds__(1024) void multibox_select_kernel(const float* __restrict__ terms, const int* __restrict__ cnt, int N,
-                                                               int P, float alpha, float* __restrict__ sel) {
+                                                               int P, float alpha, float* __restrict__ sel, int single) {
     extern __shared__ unsigned lds_u[];
-    unsigned* vpos = lds_u;           // P
-    unsigned* vneg = lds_u + P;       // P
-    unsigned* hist = lds_u + 2 * P;   // 256
-    unsigned* bcast = hist + 256;     // 2
-    double* red = reinterpret_cast<double*>(bcast + 2 + ((2 * P + 258) & 1));  // 16 doubles, 8B aligned
+    const int rows = single ? 1 : 2;
+    unsigned* vpos = lds_u;                          // P
+    unsigned* vneg = single ? lds_u : lds_u + P;     // P
+    unsigned* hist = lds_u + rows * P;               // 256
+    unsigned* bcast = hist + 256;                    // 2
+    double* red = reinterpret_cast<double*>(bcast + 2 + ((rows * P + 258) & 1));  // 16 doubles, 8B aligned
     const int n = blockIdx.x;
     const size_t np = (size_t)N * P;
     const float* l_loc = terms + (size_t)n * P;
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(1024) void multibox_select_kernel(const float* __re
     const float* l_neg = terms + 2 * np + (size_t)n * P;
     for (int i = threadIdx.x; i < P; i += blockDim.x) {
         vpos[i] = canon_bits(l_pos[i]);
-        vneg[i] = canon_bits(l_neg[i]);
+        if (!single) vneg[i] = canon_bits(l_neg[i]);
     }
     // SSD._split_pos_neg, ssd.py:300-311 (integer exact)
     int pos = cnt[n], neg = P - pos;
@@ -225,12 +227,17 @@ __global__ __launch_bounds__(1024) void multibox_select_kernel(const float* __re
     __syncthreads();
     // SSD._k_plus_1_th_value, ssd.py:313-328: kthvalue(P-k) ascending == (k+1)-th largest; k == 0 -> max == 1st largest
     unsigned tp = radix_select_desc(vpos, P, pos_k + 1, hist, bcast);
+    if (single) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < P; i += blockDim.x) vneg[i] = canon_bits(l_neg[i]);
+        __syncthreads();
+    }
     unsigned tn = radix_select_desc(vneg, P, neg_k + 1, hist, bcast);
     float thr_pos = __uint_as_float(tp), thr_neg = __uint_as_float(tn);
     // ssd.py:226-227 masked sum for this image
     double acc = 0.0;
     for (int i = threadIdx.x; i < P; i += blockDim.x) {
-        float lp = __uint_as_float(vpos[i]), ln = __uint_as_float(vneg[i]);
+        float lp = __uint_as_float(canon_bits(l_pos[i])), ln = __uint_as_float(vneg[i]);
         float v = 0.0f;
         if (lp > thr_pos) v += alpha * l_loc[i] + lp;
         if (ln > thr_neg) v += ln;
@@ -355,7 +362,7 @@ int ssdhip_default_boxes(float* out, const int32_t* maps_host, int n_maps, doubl
 int ssdhip_multibox_loss_fwd(const float* outputs, const float* targets, const float* dboxes, int N, int P, int G, int C,
                              float alpha, float threshold, float* terms, int32_t* cnt, float* sel, float* loss, void* stream) {
     SSDHIP_REQUIRE(outputs && targets && dboxes && terms && cnt && sel && loss, "multibox_loss_fwd: null pointer");
-    SSDHIP_REQUIRE(N > 0 && P > 0 && P <= 16384 && G >= 0, "multibox_loss_fwd: need 0 < P <= 16384");
+    SSDHIP_REQUIRE(N > 0 && P > 0 && P <= 32768 && G >= 0, "multibox_loss_fwd: need 0 < P <= 32768");
     SSDHIP_REQUIRE(C == 21, "multibox_loss_fwd: built for C = 21 (20 VOC classes + void)");
     SSDHIP_REQUIRE((size_t)G * (4 + C) * 4 <= 64 * 1024, "multibox_loss_fwd: G too large for LDS staging");
     hipStream_t st = (hipStream_t)stream;
@@ -364,8 +371,15 @@ int ssdhip_multibox_loss_fwd(const float* outputs, const float* targets, const f
     hipLaunchKernelGGL(multibox_terms_kernel<21>, dim3(cdiv(P, 256), N), dim3(256), lds, st, outputs, targets, dboxes, P, G, alpha,
                        threshold, terms, cnt, N);
     SSDHIP_CHECK_LAUNCH();
-    size_t lds2 = ((size_t)2 * P + 258 + 2) * 4 + 16 * 8 + 8;
-    hipLaunchKernelGGL(multibox_select_kernel, dim3(N), dim3(1024), lds2, st, terms, cnt, N, P, alpha, sel);
+    const int single = P > 16384;                       // two staged rows fit the 160 KiB LDS up to P = 16,384
+    size_t lds2 = ((size_t)(single ? 1 : 2) * P + 258 + 2) * 4 + 16 * 8 + 8;
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(multibox_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+            hipSuccess) { ssdhip_set_error("multibox_loss_fwd: cannot raise the dynamic LDS limit"); return SSDHIP_ELAUNCH; }
+        lds_attr_set = true;
+    }
+    hipLaunchKernelGGL(multibox_select_kernel, dim3(N), dim3(1024), lds2, st, terms, cnt, N, P, alpha, sel, single);
     SSDHIP_CHECK_LAUNCH();
     hipLaunchKernelGGL(multibox_mean_kernel, dim3(1), dim3(64), 0, st, sel, N, loss);
     SSDHIP_CHECK_LAUNCH();

@@ -79,6 +79,9 @@ constexpr int NMS_THREADS = 1024;
 constexpr int NMS_WAVES = NMS_THREADS / 64;
 constexpr int NMS_LDS_BYTES = 160 * 1024;
 constexpr int NMS_MISC_BYTES = 64 * 8 + NMS_WAVES * 8 + 64;  // rowmask[64], wmask[16], scalars
+constexpr int NMS_WS_SMALL_P = 9984;     // up to here the LDS-resident sort / scan kernels of the workspace variant apply
+constexpr int NMS_WS_MAX_P = 32768;      // large-P kernels (SSD512: 24,564 priors): chunked sort, scan on global mask rows
+constexpr int SORT_CHUNK = 16384;        // keys per LDS residency of the chunked bitonic sort (128 KiB)
 
 __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(float* __restrict__ outputs, int P, int C, float thr,
                                                           uint8_t* __restrict__ keep_out, int idx_bytes, int kept_cap) {
@@ -223,7 +226,8 @@ struct NmsWs {
     float4* sbox;          // (N, P) boxes in sorted order
     unsigned char* flag;   // (N, P) keep flags by prior index
     unsigned long long* mask;   // (N, P, W) W = ceil(P / 64)
-    int W;
+    unsigned long long* keys;   // (N, sortcap) sort keys in global memory, large-P variant only (P > NMS_WS_SMALL_P)
+    int W, sortcap;
 };
 
 __global__ __launch_bounds__(NMS_THREADS) void nms_sort_kernel(const float* __restrict__ outputs, int P, int C, NmsWs ws) {
@@ -387,13 +391,144 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(float* __restrict__ outpu
     }
 }
 
+// ---- large-P variant (NMS_WS_SMALL_P < P <= NMS_WS_MAX_P; the SSD512 extension).  Same keys, same mask kernel, same keep set;
+// the sort keeps its keys in the workspace and visits them in 16,384-key LDS residencies (bitonic steps with a stride below
+// the chunk run in LDS, the few wider ones on global memory), and the scan reads mask rows from global memory / L2.
+__device__ void bitonic_steps_lds(unsigned long long* keys, int base, int n, int k, int jstart) {
+    for (int j = jstart; j > 0; j >>= 1) {
+        for (int t = threadIdx.x; t < (n >> 1); t += NMS_THREADS) {
+            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+            const unsigned long long a = keys[i], b = keys[l];
+            const bool desc = ((base + i) & k) == 0;
+            if ((a < b) == desc) { keys[i] = b; keys[l] = a; }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(NMS_THREADS) void nms_sort_big_kernel(const float* __restrict__ outputs, int P, int C, NmsWs ws) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned long long* lk = reinterpret_cast<unsigned long long*>(lds);
+    __shared__ int cnt;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int ROW = 4 + C;
+    const float* out = outputs + (size_t)n * P * ROW;
+    unsigned long long* gk = ws.keys + (size_t)n * ws.sortcap;
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    for (int i = tid; i < P; i += NMS_THREADS) {
+        const float* row = out + (size_t)i * ROW;
+        float sc = row[5];
+        for (int c = 6; c < ROW; ++c) sc = fmaxf(sc, row[c]);
+        ws.flag[(size_t)n * P + i] = 0;
+        if (sc > 0.0f) {
+            const int slot = atomicAdd(&cnt, 1);
+            gk[slot] = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+        }
+    }
+    __syncthreads();
+    const int K = cnt;
+    int sortn = 64;
+    while (sortn < K) sortn <<= 1;
+    for (int i = K + tid; i < sortn; i += NMS_THREADS) gk[i] = 0ull;
+    __syncthreads();
+    const int ch = min(sortn, SORT_CHUNK);
+    for (int c0 = 0; c0 < sortn; c0 += ch) {                 // every phase that fits one chunk, in one residency per chunk
+        for (int i = tid; i < ch; i += NMS_THREADS) lk[i] = gk[c0 + i];
+        __syncthreads();
+        for (int k = 2; k <= ch; k <<= 1) bitonic_steps_lds(lk, c0, ch, k, k >> 1);
+        for (int i = tid; i < ch; i += NMS_THREADS) gk[c0 + i] = lk[i];
+        __syncthreads();
+    }
+    for (int k = ch << 1; k <= sortn; k <<= 1) {
+        for (int j = k >> 1; j >= ch; j >>= 1) {             // strides that cross chunks: on global memory
+            for (int t = tid; t < (sortn >> 1); t += NMS_THREADS) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                const unsigned long long a = gk[i], b = gk[l];
+                const bool desc = (i & k) == 0;
+                if ((a < b) == desc) { gk[i] = b; gk[l] = a; }
+            }
+            __syncthreads();
+        }
+        for (int c0 = 0; c0 < sortn; c0 += ch) {
+            for (int i = tid; i < ch; i += NMS_THREADS) lk[i] = gk[c0 + i];
+            __syncthreads();
+            bitonic_steps_lds(lk, c0, ch, k, ch >> 1);
+            for (int i = tid; i < ch; i += NMS_THREADS) gk[c0 + i] = lk[i];
+            __syncthreads();
+        }
+    }
+    if (tid == 0) ws.count[n] = K;
+    for (int i = tid; i < K; i += NMS_THREADS) {
+        const int idx = (int)(0xFFFFFFFFu - (unsigned)(gk[i] & 0xFFFFFFFFull));
+        const float* row = out + (size_t)idx * ROW;
+        ws.sidx[(size_t)n * P + i] = idx;
+        ws.sbox[(size_t)n * P + i] = make_float4(row[0], row[1], row[2], row[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void nms_scan_big_kernel(float* __restrict__ outputs, int P, int C, NmsWs ws, unsigned char* __restrict__ keep_out) {
+    __shared__ unsigned long long rem[NMS_WS_MAX_P / 64];
+    __shared__ unsigned long long surv;
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = ws.count[n];
+    const int ROW = 4 + C, W = ws.W, WK = (K + 63) >> 6;
+    const unsigned long long* mrow = ws.mask + (size_t)n * P * W;
+    const int* sidx = ws.sidx + (size_t)n * P;
+    unsigned char* flag = ws.flag + (size_t)n * P;
+    for (int i = tid; i < WK; i += 256) rem[i] = 0ull;
+    __syncthreads();
+    for (int bt = 0; bt < WK; ++bt) {
+        if (wave == 0) {
+            const int left = K - bt * 64;
+            const unsigned long long valid = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+            unsigned long long alive = valid & ~rem[bt];
+            const unsigned long long diag = lane < left ? mrow[(size_t)(bt * 64 + lane) * W + bt] : 0ull;
+            const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+#pragma unroll
+            for (int i = 0; i < 64; ++i) {
+                const unsigned lo = __builtin_amdgcn_readlane(dlo, i);
+                const unsigned hi = __builtin_amdgcn_readlane(dhi, i);
+                if ((alive >> i) & 1ull) alive &= ~(((unsigned long long)hi << 32) | lo);
+            }
+            if (lane == 0) surv = alive;
+        }
+        __syncthreads();
+        const unsigned long long kw0 = surv;
+        if (tid < 64 && ((kw0 >> tid) & 1ull)) flag[sidx[bt * 64 + tid]] = 1;
+        for (int w = bt + 1 + tid; w < WK; w += 256) {
+            unsigned long long kw = kw0, acc = 0ull;
+            while (kw) {
+                const int r = __ffsll((long long)kw) - 1;
+                kw &= kw - 1;
+                acc |= mrow[(size_t)(bt * 64 + r) * W + w];
+            }
+            rem[w] |= acc;
+        }
+        __syncthreads();
+    }
+    float* out = outputs + (size_t)n * P * ROW;
+    for (int i = tid; i < P; i += 256) {
+        const bool k = flag[i] != 0;
+        if (keep_out) keep_out[(size_t)n * P + i] = k ? 1 : 0;
+        if (!k) {
+            float* row = out + (size_t)i * ROW;
+            for (int c = 4; c < ROW; ++c) row[c] = row[c] * 0.0f;
+        }
+    }
+}
+
 size_t nms_ws_layout(int N, int P, NmsWs* ws, unsigned char* base) {
     const int W = ((P + 63) / 64 + 1) / 2 * 2;      // even: mask rows stay 16-B aligned
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     const size_t o_count = take((size_t)N * 4), o_sidx = take((size_t)N * P * 4), o_sbox = take((size_t)N * P * 16);
     const size_t o_flag = take((size_t)N * P), o_mask = take((size_t)N * P * W * 8);
+    int sortcap = 0;
+    if (P > NMS_WS_SMALL_P) { sortcap = 64; while (sortcap < P) sortcap <<= 1; }
+    const size_t o_keys = take((size_t)N * sortcap * 8);
     if (ws) {
+        ws->keys = reinterpret_cast<unsigned long long*>(base + o_keys); ws->sortcap = sortcap;
         ws->count = reinterpret_cast<int*>(base + o_count); ws->sidx = reinterpret_cast<int*>(base + o_sidx);
         ws->sbox = reinterpret_cast<float4*>(base + o_sbox); ws->flag = base + o_flag;
         ws->mask = reinterpret_cast<unsigned long long*>(base + o_mask); ws->W = W;
@@ -429,14 +564,16 @@ int64_t ssdhip_nms_ws_bytes(int N, int P) {
 
 int ssdhip_nms_ws(float* outputs, int N, int P, int C, float iou_thresh, uint8_t* keep, void* ws_ptr, void* stream) {
     SSDHIP_REQUIRE(outputs && ws_ptr && N > 0 && P > 0 && C >= 2, "nms_ws: bad arguments");
-    SSDHIP_REQUIRE(P <= 9984, "nms_ws: P <= 9984 (two 64-row batches of the bit-matrix must fit 160 KiB of LDS; 192 word-pair loaders)");
+    SSDHIP_REQUIRE(P <= NMS_WS_MAX_P, "nms_ws: P <= 32768");
     SSDHIP_REQUIRE(N <= 65535, "nms_ws: N <= 65535");
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(nms_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 NMS_LDS_BYTES) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                128 * 1024) != hipSuccess) {
+                                128 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                SORT_CHUNK * 8) != hipSuccess) {
             ssdhip_set_error("nms_ws: cannot enable 128 KiB dynamic LDS");
             return SSDHIP_ELAUNCH;
         }
@@ -445,15 +582,24 @@ int ssdhip_nms_ws(float* outputs, int N, int P, int C, float iou_thresh, uint8_t
     NmsWs ws;
     nms_ws_layout(N, P, &ws, reinterpret_cast<unsigned char*>(ws_ptr));
     hipStream_t st = (hipStream_t)stream;
-    int sortn = 64;
-    while (sortn < P) sortn <<= 1;
-    hipLaunchKernelGGL(nms_sort_kernel, dim3(N), dim3(NMS_THREADS), (size_t)sortn * 8, st, outputs, P, C, ws);
-    SSDHIP_CHECK_LAUNCH();
     const int chunks = (P + 63) / 64;
-    hipLaunchKernelGGL(nms_mask_kernel, dim3((chunks + 3) / 4, chunks, N), dim3(256), 0, st, P, iou_thresh, ws);
-    SSDHIP_CHECK_LAUNCH();
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(N), dim3(256), (size_t)2 * 64 * ws.W * 8 + 16, st, outputs, P, C, ws, keep);
-    SSDHIP_CHECK_LAUNCH();
+    if (P <= NMS_WS_SMALL_P) {      // two 64-row batches of the bit-matrix fit 160 KiB of LDS; 192 word-pair loaders
+        int sortn = 64;
+        while (sortn < P) sortn <<= 1;
+        hipLaunchKernelGGL(nms_sort_kernel, dim3(N), dim3(NMS_THREADS), (size_t)sortn * 8, st, outputs, P, C, ws);
+        SSDHIP_CHECK_LAUNCH();
+        hipLaunchKernelGGL(nms_mask_kernel, dim3((chunks + 3) / 4, chunks, N), dim3(256), 0, st, P, iou_thresh, ws);
+        SSDHIP_CHECK_LAUNCH();
+        hipLaunchKernelGGL(nms_scan_kernel, dim3(N), dim3(256), (size_t)2 * 64 * ws.W * 8 + 16, st, outputs, P, C, ws, keep);
+        SSDHIP_CHECK_LAUNCH();
+    } else {
+        hipLaunchKernelGGL(nms_sort_big_kernel, dim3(N), dim3(NMS_THREADS), (size_t)SORT_CHUNK * 8, st, outputs, P, C, ws);
+        SSDHIP_CHECK_LAUNCH();
+        hipLaunchKernelGGL(nms_mask_kernel, dim3((chunks + 3) / 4, chunks, N), dim3(256), 0, st, P, iou_thresh, ws);
+        SSDHIP_CHECK_LAUNCH();
+        hipLaunchKernelGGL(nms_scan_big_kernel, dim3(N), dim3(256), 0, st, outputs, P, C, ws, keep);
+        SSDHIP_CHECK_LAUNCH();
+    }
     return SSDHIP_OK;
 }
 

@@ -60,8 +60,8 @@ class Engine:
         self.lib = _lib.load()
         self.nc = module.num_classes
         self.row = self.nc + 4
-        plan = T.feature_plan()
-        heads = {h['tag']: (i, h) for i, h in enumerate(T.head_plan(self.nc))}
+        plan = T.feature_plan(module.topo)
+        heads = {h['tag']: (i, h) for i, h in enumerate(T.head_plan(self.nc, module.topo))}
         self.stages = []
         i = 0
         while i < len(plan):

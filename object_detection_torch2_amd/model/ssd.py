@@ -84,18 +84,20 @@ class _MultiBoxLoss(torch.autograd.Function):
 
 
 class SSD(nn.Module):
-    def __init__(self, num_classes: int, weights_path: pathlib.Path = None, weights_path_vgg16: pathlib.Path = None):
+    def __init__(self, num_classes: int, weights_path: pathlib.Path = None, weights_path_vgg16: pathlib.Path = None, imsize: int = 300):
         """Same arguments as the reference (ssd.py:9).  weights_path_vgg16: local VGG16 state-dict (the reference's
-        vgg16.py:64-66 branch); its `features.N.*` entries initialise the frozen backbone."""
+        vgg16.py:64-66 branch); its `features.N.*` entries initialise the frozen backbone.
+        imsize (extension, default = the reference's 300): 512 builds the 24,564-prior SSD512 variant (topology.SSD512)."""
         super(SSD, self).__init__()
         self.num_classes = num_classes
+        self.topo = T.topology_for(imsize)
         self._hip_epoch = 0
         self._eng = None
         self._engine_token = None
         self._default_bboxes = None      # generated lazily by the HIP kernel (first access needs the GPU)
 
         features = nn.ModuleDict()
-        for l in T.feature_plan():
+        for l in T.feature_plan(self.topo):
             if l['kind'] == 'conv':
                 m = nn.Conv2d(in_channels=l['cin'], out_channels=l['cout'], kernel_size=l['k'], stride=l['stride'], padding=l['pad'])
             elif l['kind'] == 'bn':
@@ -110,7 +112,7 @@ class SSD(nn.Module):
             features[l['name']] = m
         self.features = features
         self.detectors = nn.ModuleDict({
-            h['name']: nn.Conv2d(in_channels=h['cin'], out_channels=h['cout'], kernel_size=3, padding=1) for h in T.head_plan(num_classes)})
+            h['name']: nn.Conv2d(in_channels=h['cin'], out_channels=h['cout'], kernel_size=3, padding=1) for h in T.head_plan(num_classes, self.topo)})
 
         self._initialize_weights()
         if weights_path_vgg16 and pathlib.Path(weights_path_vgg16).exists():
@@ -138,7 +140,7 @@ class SSD(nn.Module):
         own = self.state_dict()
         idx, stage, sub = 0, 1, 1
         with torch.no_grad():
-            for v in T.VGG_CFG:
+            for v in self.topo.vgg_cfg:
                 if isinstance(v, str):
                     idx, stage, sub = idx + 1, stage + 1, 1
                     continue
@@ -160,15 +162,15 @@ class SSD(nn.Module):
         Callers move it with `.to(device)` like the reference (train.py:81)."""
         if not torch.cuda.is_available():
             raise RuntimeError('SSD needs an MI355X: default boxes are generated by libssdhip.so (no CPU fallback)')
-        return self.default_bboxes_on(torch.device('cuda', torch.cuda.current_device())).cpu()
+        return self.default_bboxes_on(torch.device('cuda', torch.cuda.current_device()), self.topo).cpu()
 
     @staticmethod
-    def default_bboxes_on(device) -> torch.Tensor:
+    def default_bboxes_on(device, topo=T.SSD300) -> torch.Tensor:
         import ctypes
-        maps = (ctypes.c_int32 * (3 * len(T.BOX_MAPS)))(*[v for m in T.BOX_MAPS for v in m])
-        out = torch.empty(T.num_priors(), 4, device=device, dtype=torch.float32)
+        maps = (ctypes.c_int32 * (3 * len(topo.box_maps)))(*[v for m in topo.box_maps for v in m])
+        out = torch.empty(topo.num_priors(), 4, device=device, dtype=torch.float32)
         with torch.cuda.device(device):
-            _lib.check(_lib.load().ssdhip_default_boxes(_lib.ptr(out), maps, len(T.BOX_MAPS), T.S_MIN, T.S_MAX, _lib.stream()),
+            _lib.check(_lib.load().ssdhip_default_boxes(_lib.ptr(out), maps, len(topo.box_maps), topo.s_min, topo.s_max, _lib.stream()),
                        'default_boxes')
         return out
 

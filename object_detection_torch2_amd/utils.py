@@ -82,7 +82,7 @@ def non_maximum_suppression(outputs: torch.Tensor, iou_thresh: float = 0.5, retu
     """utils.py:80-116: greedy class-agnostic NMS; zeroes outputs[:, :, 4:] of suppressed / void rows IN PLACE and
     returns `outputs` (the same object), like the reference.
     variant: 'lds' (one workgroup per image, everything in LDS), 'ws' (bit-matrix over the whole chip + serial scan,
-    cached workspace) or 'auto' (ws for P <= 9984)."""
+    cached workspace; P <= 32768) or 'auto' (= ws)."""
     _lib.require_gpu(outputs)
     if outputs.dim() != 3 or outputs.shape[2] < 6:
         raise ValueError(f'expected (N, P, 4 + C) with C >= 2, got {tuple(outputs.shape)}')
@@ -90,7 +90,7 @@ def non_maximum_suppression(outputs: torch.Tensor, iou_thresh: float = 0.5, retu
     N, P, row = work.shape
     keep = torch.empty(N, P, dtype=torch.uint8, device=work.device)
     lib = _lib.load()
-    if variant == 'ws' or (variant == 'auto' and P <= 9984):
+    if variant in ('ws', 'auto'):
         key = (N, P, str(work.device))
         ws = _nms_ws.get(key)
         if ws is None:

@@ -28,14 +28,23 @@ EXTRA_CFG = [[(3, 1024, 1, 1)], [(1, 1024, 1, 0)], [(1, 256, 1, 0), (3, 512, 2, 
              [(1, 128, 1, 0), (3, 256, 2, 1)], [(1, 128, 1, 0), (3, 256, 1, 0)], [(1, 128, 1, 0), (3, 256, 1, 0)]]
 DET_CFG = [('4_3', 512, 4), ('7_1', 1024, 6), ('8_2', 512, 6), ('9_2', 256, 6), ('10_2', 256, 4), ('11_2', 256, 4)]
 BOX_CFG = [[38, 38, 4], [19, 19, 6], [10, 10, 6], [5, 5, 6], [3, 3, 4], [1, 1, 4]]
+# SSD512 (build-side extension, no reference: ssd.py:118 hard-codes the 300-px grid): BASELINE configs[4]'s 24,564 priors =
+# maps 64/32/16/8/4/2/1; pool_3 without padding, five stride-2 extras.  Same rules as above otherwise.
+TOPOLOGIES = {
+    300: dict(vgg=VGG_CFG, extra=EXTRA_CFG, det=DET_CFG, box=BOX_CFG),
+    512: dict(vgg=[64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M_P'],
+              extra=[[(3, 1024, 1, 1)], [(1, 1024, 1, 0)], [(1, 256, 1, 0), (3, 512, 2, 1)]] + [[(1, 128, 1, 0), (3, 256, 2, 1)]] * 4,
+              det=[('4_3', 512, 4), ('7_1', 1024, 6), ('8_2', 512, 6), ('9_2', 256, 6), ('10_2', 256, 6), ('11_2', 256, 4), ('12_2', 256, 4)],
+              box=[[64, 64, 4], [32, 32, 6], [16, 16, 6], [8, 8, 6], [4, 4, 6], [2, 2, 4], [1, 1, 4]]),
+}
 MEAN = (0.485, 0.456, 0.406)
 STD = (0.229, 0.224, 0.225)
 
 
-def feature_layers():
+def feature_layers(imsize=300):
     """Ordered feature layer table: dicts with kind conv/bn/act/pool (ssd.py:28-66)."""
     layers, cin, stage, sub = [], 3, 1, 1
-    for v in VGG_CFG:
+    for v in TOPOLOGIES[imsize]['vgg']:
         if v in ('M', 'M_P'):
             if stage < 5:                                   # pool_5 dropped, ssd.py:38
                 layers.append(dict(kind='pool', name=f'pool_{stage}', pad=1 if v == 'M_P' else 0))
@@ -46,7 +55,7 @@ def feature_layers():
             layers.append(dict(kind='bn', name=f'bn_{tag}', c=v, frozen=True))
             layers.append(dict(kind='act', name=f'act_{tag}'))
             cin, sub = v, sub + 1
-    for group in EXTRA_CFG:
+    for group in TOPOLOGIES[imsize]['extra']:
         sub = 1
         for (k, v, s, p) in group:
             tag = f'{stage}_{sub}'
@@ -58,17 +67,17 @@ def feature_layers():
     return layers
 
 
-def detector_layers(num_classes=21):
-    return [dict(name=f'det_{t}', src=f'act_{t}', cin=c, cout=a * (num_classes + 4), anchors=a) for t, c, a in DET_CFG]
+def detector_layers(num_classes=21, imsize=300):
+    return [dict(name=f'det_{t}', src=f'act_{t}', cin=c, cout=a * (num_classes + 4), anchors=a) for t, c, a in TOPOLOGIES[imsize]['det']]
 
 
-def trainable_param_names(num_classes=21):
+def trainable_param_names(num_classes=21, imsize=300):
     """Order of SSD.train_params() (ssd.py:160-179)."""
     out = []
-    for l in feature_layers():
+    for l in feature_layers(imsize):
         if l['kind'] in ('conv', 'bn') and not l['frozen']:
             out += [f"features.{l['name']}.weight", f"features.{l['name']}.bias"]
-    for d in detector_layers(num_classes):
+    for d in detector_layers(num_classes, imsize):
         out += [f"detectors.{d['name']}.weight", f"detectors.{d['name']}.bias"]
     return out
 
@@ -76,11 +85,13 @@ def trainable_param_names(num_classes=21):
 # ----------------------------------------------------------------------------
 # A9 default boxes (ssd.py:108-133): python doubles rounded once to fp32
 # ----------------------------------------------------------------------------
-def default_bboxes():
-    def s_(k, m=6, s_min=0.2, s_max=0.9):
+def default_bboxes(imsize=300):
+    box_cfg = TOPOLOGIES[imsize]['box']
+
+    def s_(k, m=len(box_cfg), s_min=0.2, s_max=0.9):
         return s_min + (s_max - s_min) * (k - 1) / (m - 1)
     rows = []
-    for k, (m, n, a_num) in enumerate(BOX_CFG, start=1):
+    for k, (m, n, a_num) in enumerate(box_cfg, start=1):
         aspects = [1, 2, 1 / 2, 'add'] if a_num == 4 else [1, 2, 1 / 2, 3, 1 / 3, 'add']
         for i in range(m):
             for j in range(n):
@@ -281,7 +292,7 @@ def non_maximum_suppression(outputs, iou_thresh=0.5):
 # ----------------------------------------------------------------------------
 # A2-A8 forward on torch CPU ops (floating-point layers)
 # ----------------------------------------------------------------------------
-def init_state(seed=1, num_classes=21, vgg_random=True):
+def init_state(seed=1, num_classes=21, vgg_random=True, imsize=300):
     """Reference-keyed state_dict (173 entries) with hash-seeded weights: kaiming fan_out pseudo-normal for every
     conv (the VGG part too -- no pretrained weights exist offline), bias 0, BN gamma 1 / beta 0 / stats 0,1."""
     import torch
@@ -294,7 +305,7 @@ def init_state(seed=1, num_classes=21, vgg_random=True):
         stream += 1
         sd[prefix + '.weight'] = torch.from_numpy(w.astype(f32).reshape(cout, cin, k, k))
         sd[prefix + '.bias'] = torch.zeros(cout)
-    for l in feature_layers():
+    for l in feature_layers(imsize):
         if l['kind'] == 'conv':
             conv('features.' + l['name'], l['cout'], l['cin'], l['k'])
         elif l['kind'] == 'bn':
@@ -302,12 +313,12 @@ def init_state(seed=1, num_classes=21, vgg_random=True):
             sd[p + '.weight'] = torch.ones(l['c']); sd[p + '.bias'] = torch.zeros(l['c'])
             sd[p + '.running_mean'] = torch.zeros(l['c']); sd[p + '.running_var'] = torch.ones(l['c'])
             sd[p + '.num_batches_tracked'] = torch.tensor(0, dtype=torch.long)
-    for d in detector_layers(num_classes):
+    for d in detector_layers(num_classes, imsize):
         conv('detectors.' + d['name'], d['cout'], d['cin'], 3)
     return sd
 
 
-def forward(sd, x, num_classes=21, training=True, collect=None):
+def forward(sd, x, num_classes=21, training=True, collect=None, imsize=300):
     """Intended SSD.forward contract (N,P,4+C) (ssd.py:86-106 with the Q1 membership fix).
     sd: state dict of torch tensors (requires_grad honoured); running stats updated in place when training."""
     import torch
@@ -315,9 +326,9 @@ def forward(sd, x, num_classes=21, training=True, collect=None):
     mean = torch.tensor(MEAN, dtype=torch.float32).reshape(1, 3, 1, 1)
     std = torch.tensor(STD, dtype=torch.float32).reshape(1, 3, 1, 1)
     x = x.sub(mean).div(std)                                          # vgg16.py:112-114
-    dets = {d['src']: d for d in detector_layers(num_classes)}
+    dets = {d['src']: d for d in detector_layers(num_classes, imsize)}
     ys = []
-    for l in feature_layers():
+    for l in feature_layers(imsize):
         p = 'features.' + l['name']
         if l['kind'] == 'conv':
             x = F.conv2d(x, sd[p + '.weight'], sd[p + '.bias'], stride=l['stride'], padding=l['pad'])
@@ -350,14 +361,14 @@ def adam_step(p, g, m, v, step, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, wd=5e-4):
     return p
 
 
-def train_step(sd, opt_state, images, targets_np, df, lr=1e-3, wd=5e-4, num_classes=21):
+def train_step(sd, opt_state, images, targets_np, df, lr=1e-3, wd=5e-4, num_classes=21, imsize=300):
     """One reference train-loop body (train.py:115-122) on CPU: forward -> loss -> backward -> Adam.
     Loss value and dL/d outputs come from the numpy restatement; torch autograd carries it through the layers."""
     import torch
-    names = trainable_param_names(num_classes)
+    names = trainable_param_names(num_classes, imsize)
     for k in names:
         sd[k].requires_grad_(True); sd[k].grad = None
-    out = forward(sd, images, num_classes, training=True)
+    out = forward(sd, images, num_classes, training=True, imsize=imsize)
     o = out.detach().numpy()
     lval = loss(o, targets_np, df)
     out.backward(torch.from_numpy(loss_grad(o, targets_np, df)))

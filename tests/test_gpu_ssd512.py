@@ -1,0 +1,95 @@
+"""SSD512 variant (BASELINE configs[4]; build-side extension -- the reference hard-codes the 300-px grid, ssd.py:118, so
+there is no reference output to pin: parity is against the oracle's restatement of the same layer rules on a 512-px
+input, torch CPU ops).  24,564 priors = maps 64/32/16/8/4/2/1 x anchors 4/6/6/6/6/4/4."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def env():
+    from oracle import ssd_oracle as O
+    from object_detection_torch2_amd import synth
+    from object_detection_torch2_amd.model import SSD
+    net = SSD(num_classes=21, imsize=512)
+    net.load_state_dict(O.init_state(seed=1, imsize=512))
+    return dict(O=O, synth=synth, net=net.to(DEV))
+
+
+def test_ssd512_layout(env):
+    net, O = env['net'], env['O']
+    assert list(net.detectors.keys()) == ['det_4_3', 'det_7_1', 'det_8_2', 'det_9_2', 'det_10_2', 'det_11_2', 'det_12_2']
+    assert 'conv_12_2' in net.features and net.features['conv_12_2'].stride == (2, 2) and net.features['pool_3'].padding == 0
+    assert len(net.state_dict()) == 189
+    assert [k for k, _ in net.named_train_params()] == O.trainable_param_names(imsize=512)
+    df = net.default_bboxes
+    assert df.shape == (24564, 4) and np.array_equal(df.numpy(), O.default_bboxes(512))
+    with pytest.raises(ValueError):
+        type(net)(num_classes=21, imsize=416)
+
+
+def test_ssd512_forward_and_step_vs_oracle(env):
+    net, O, synth = env['net'], env['O'], env['synth']
+    sd = O.init_state(seed=1, imsize=512)
+    names = O.trainable_param_names(imsize=512)
+    ims = synth.images(61, 2, 512)
+    tg = synth.targets(62, 2, g_max=8)
+    df = O.default_bboxes(512)
+    for k in names:
+        sd[k].requires_grad_(True)
+    out_o = O.forward(sd, torch.from_numpy(ims), training=True, imsize=512)
+    o = out_o.detach().numpy()
+    out_o.backward(torch.from_numpy(O.loss_grad(o, tg, df)))
+    out = net(torch.from_numpy(ims).to(DEV))
+    assert tuple(out.shape) == (2, 24564, 25)
+    # same bound as the SSD300 forward test: fp32 convs with K up to 4608 through 20+ layers, outputs of magnitude ~10
+    assert np.abs(out.detach().cpu().numpy() - o).max() < 2e-3
+    loss = net.loss(out, torch.from_numpy(tg).to(DEV), torch.from_numpy(df).to(DEV))
+    assert abs(loss.item() - float(O.loss(o, tg, df))) < 2e-3
+    loss.backward()
+    got = dict(net.named_train_params())
+    for k in names:
+        if 'features.conv' in k and k.endswith('.bias'):
+            continue                                        # analytically zero (BN cancels the conv bias)
+        g, r = got[k].grad.cpu().double(), sd[k].grad.double()
+        rel = ((g - r).norm() / r.norm()).item()
+        cos = (g * r).sum().item() / (g.norm().item() * r.norm().item())
+        tol = 1e-3 if k.startswith('detectors.') else 5e-2   # ReLU-flip conditioning, see test_gpu_model.py
+        assert rel < tol and cos > 0.998, (k, rel, cos)
+    stats = net.state_dict()
+    for k in ('features.bn_4_3.running_mean', 'features.bn_12_2.running_var'):
+        assert np.allclose(stats[k].cpu().numpy(), sd[k].numpy(), rtol=2e-4, atol=2e-5), k
+
+
+def test_ssd512_inference_path(env):
+    from object_detection_torch2_amd import utils
+    net, synth = env['net'], env['synth']
+    with torch.no_grad():
+        out = net(torch.from_numpy(synth.images(63, 2, 512)).to(DEV))
+        utils.decode_score_(out, net.default_bboxes.to(DEV))
+        _, keep = utils.non_maximum_suppression(out, return_keep=True)     # P = 24,564 > 9,984: the all-LDS variant's limit?
+    assert tuple(keep.shape) == (2, 24564) and keep.sum() > 0
+
+
+@pytest.mark.parametrize('P,bias,seed', [(24564, 3.0, 71), (24564, 0.0, 72), (12000, 0.0, 73)])
+def test_large_prior_set_nms_keep_set_exact(env, P, bias, seed):
+    """Large-P NMS kernels (chunked sort, scan on global mask rows; 9,984 < P <= 32,768): keep set identical to the oracle's
+    greedy loop on the same decoded boxes -- sparse (void-biased, ~1/7 of the priors are candidates) and dense (~20/21)."""
+    from object_detection_torch2_amd import utils
+    O, synth = env['O'], env['synth']
+    raw = synth.logits(seed, 1, p=P, void_bias=bias, loc_scale=0.3)
+    df = O.default_bboxes(512)
+    df = np.concatenate([df, df])[:P] if P > len(df) else df[:P]
+    pre = np.concatenate([O.calc_coordicate(raw, df), O.calc_score(raw)], axis=2)
+    want = np.zeros(P, dtype=bool)
+    want[O.nms_keep(pre[0])] = True
+    t = torch.from_numpy(pre).to(DEV)
+    ret, keep = utils.non_maximum_suppression(t, return_keep=True)
+    assert ret is t
+    got = keep.cpu().numpy()[0].astype(bool)
+    assert got.sum() == want.sum() and np.array_equal(got, want)
+    post = t.cpu().numpy()[0]
+    assert np.array_equal(post[:, :4], pre[0, :, :4]) and np.all(post[~got, 4:] == 0) and np.array_equal(post[got, 4:], pre[0][got, 4:])
