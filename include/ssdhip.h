@@ -155,7 +155,7 @@ typedef struct {
     int64_t dy_batch_stride;  /* floats between images in dy (Ho*Wo*dy_row when dense)          */
     int32_t N, Hi, Wi, Cin, Ho, Wo, Cout, R, S, stride, pad;
     int32_t dy_row;           /* floats per pixel row of dy (>= Cout, multiple of 4; channel padding) */
-    int32_t reserved;
+    int32_t dw_cin;           /* channels of dw_oihw's layout if smaller than Cin (RGB input padded to 4 in x), else 0 */
     const float* wino_v;      /* Winograd variant only: precomputed input transform V (16,Tp,Cin) of x, or NULL */
 } ssdhip_wgrad_params;
 int64_t ssdhip_conv2d_wgrad_ws_bytes(const ssdhip_wgrad_params* p);
@@ -190,6 +190,12 @@ int ssdhip_adam_multi_tensor(const void* const* table, const int64_t* sizes, con
 /* hyper (device, 8 floats): [lr, beta1, beta2, eps, weight_decay, 1-beta1^t, sqrt(1-beta2^t), grad_scale];
  * adam_tick increments the device step counter and refreshes slots 5,6 (graph-replayable step bookkeeping).  */
 int ssdhip_adam_tick(int32_t* step, float* hyper, void* stream);
+
+/* ---- 8(f)-4  full fine-tuning (train.py:69-74 un-freezes nothing; extension): backward of MaxPool2d(2,2,pad) over the
+ * recomputed a = relu(z*scale+shift) (vgg16.py:28-35): dpooled (N,Ho,Wo,C) -> da (N,H,W,C), gradient to the first maximum
+ * of each window in scan order (ATen rule).                                                                            */
+int ssdhip_bn_relu_pool_bwd(const float* z, const float* scale, const float* shift, const float* dpooled, float* da, int N, int H, int W,
+                            int C, int pool_pad, void* stream);
 
 /* ---- 8(f)-2  batch augmentation (augmentation/random.py:6-42, augmentation/to_tensor.py:8-16, applied per sample at
  * dataset.py:43-52; pipeline train.py:32-36): colour jitter ops in the sampled order, horizontal flip, uint8 -> [0,1]

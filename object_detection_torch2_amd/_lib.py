@@ -30,7 +30,7 @@ class WgradParams(Structure):
                 ('dw_oihw', c_void_p), ('dbias', c_void_p), ('ws', c_void_p), ('dy_batch_stride', c_int64),
                 ('N', c_int32), ('Hi', c_int32), ('Wi', c_int32), ('Cin', c_int32), ('Ho', c_int32), ('Wo', c_int32),
                 ('Cout', c_int32), ('R', c_int32), ('S', c_int32), ('stride', c_int32), ('pad', c_int32), ('dy_row', c_int32),
-                ('reserved', c_int32), ('wino_v', c_void_p)]
+                ('dw_cin', c_int32), ('wino_v', c_void_p)]
 
 
 # every symbol include/ssdhip.h declares: name -> (restype, argtypes)
@@ -74,6 +74,7 @@ SIGNATURES = {
     'ssdhip_scatter_head_grad': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ssdhip_adam_multi_tensor': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'ssdhip_adam_tick': (c_int, [c_void_p, c_void_p, c_void_p]),
+    'ssdhip_bn_relu_pool_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ssdhip_augment_row_floats': (c_int, []),
     'ssdhip_augment_ws_bytes': (c_int64, [c_int]),
     'ssdhip_augment_batch': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -159,6 +159,44 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float4* __restr
     y[i] = m;
 }
 
+// MaxPool2d(2,2,pad) backward fused with the recomputation of its input a = relu(z*scale+shift): one thread = one 2x2 window x
+// 4 channels; the gradient goes to the first maximum in (h, w) scan order (ATen's rule: a later element wins only if strictly
+// greater); every input pixel lies in exactly one window, pixels past the last window (odd size, no padding) get 0.
+__global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const float4* __restrict__ z, const float4* __restrict__ scale,
+                                                               const float4* __restrict__ shift, const float4* __restrict__ dpooled,
+                                                               float4* __restrict__ da, int H, int W, int C4, int Ho, int Wo, int HoE,
+                                                               int WoE, int pad, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = (int)(i % C4);
+    int64_t pix = i / C4;
+    const int wo = (int)(pix % WoE);
+    pix /= WoE;
+    const int ho = (int)(pix % HoE);
+    const int64_t n = pix / HoE;
+    const bool real = ho < Ho && wo < Wo;
+    const float4 sc = scale[c4], sh = shift[c4];
+    const float4 g = real ? dpooled[((n * Ho + ho) * Wo + wo) * C4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    int bx = -1, by = -1, bz = -1, bw = -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int h = ho * 2 - pad + (k >> 1), w = wo * 2 - pad + (k & 1);
+        if ((unsigned)h >= (unsigned)H || (unsigned)w >= (unsigned)W) continue;
+        const float4 v = bn_relu4(z[((n * H + h) * W + w) * C4 + c4], sc, sh);
+        if (v.x > best.x) { best.x = v.x; bx = k; }
+        if (v.y > best.y) { best.y = v.y; by = k; }
+        if (v.z > best.z) { best.z = v.z; bz = k; }
+        if (v.w > best.w) { best.w = v.w; bw = k; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int h = ho * 2 - pad + (k >> 1), w = wo * 2 - pad + (k & 1);
+        if ((unsigned)h >= (unsigned)H || (unsigned)w >= (unsigned)W) continue;
+        da[((n * H + h) * W + w) * C4 + c4] = make_float4(bx == k ? g.x : 0.f, by == k ? g.y : 0.f, bz == k ? g.z : 0.f, bw == k ? g.w : 0.f);
+    }
+}
+
 // ---- BN(train) + ReLU backward -----------------------------------------------------------------------------------
 // y = z*scale+shift, a = relu(y).  dy = da * (y > 0);  xhat = (z - mean) * invstd
 // pass 1: per row-block partial sums of dy and dy*xhat, layout (MBrows, C, 2)
@@ -291,6 +329,22 @@ int ssdhip_bn_fold_eval(const float* gamma, const float* beta, const float* runn
     SSDHIP_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0, "bn_fold_eval: bad arguments");
     hipLaunchKernelGGL(bn_fold_eval_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, gamma, beta, running_mean, running_var,
                        eps, C, scale, shift);
+    SSDHIP_CHECK_LAUNCH();
+    return SSDHIP_OK;
+}
+
+int ssdhip_bn_relu_pool_bwd(const float* z, const float* scale, const float* shift, const float* dpooled, float* da, int N, int H, int W,
+                            int C, int pool_pad, void* stream) {
+    SSDHIP_REQUIRE(z && scale && shift && dpooled && da && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0,
+                   "bn_relu_pool_bwd: bad arguments (C % 4 == 0)");
+    SSDHIP_REQUIRE(pool_pad == 0 || pool_pad == 1, "bn_relu_pool_bwd: pool padding 0 or 1");
+    const int C4 = C / 4;
+    const int Ho = (H + 2 * pool_pad - 2) / 2 + 1, Wo = (W + 2 * pool_pad - 2) / 2 + 1;
+    const int HoE = (H + pool_pad + 1) / 2, WoE = (W + pool_pad + 1) / 2;        // windows needed to touch every input pixel
+    int64_t total = (int64_t)N * HoE * WoE * C4;
+    hipLaunchKernelGGL(bn_relu_pool_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(z),
+                       reinterpret_cast<const float4*>(scale), reinterpret_cast<const float4*>(shift),
+                       reinterpret_cast<const float4*>(dpooled), reinterpret_cast<float4*>(da), H, W, C4, Ho, Wo, HoE, WoE, pool_pad, total);
     SSDHIP_CHECK_LAUNCH();
     return SSDHIP_OK;
 }

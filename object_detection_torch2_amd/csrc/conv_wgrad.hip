@@ -183,6 +183,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // dw_oihw[co][ci][tap] = sum_split ws[split][co][tap][ci]
+// (Cin = channels of dw's OIHW layout: the padded RGB input has 4 in x but 3 in the parameter)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int taps, int CoutT,
                                     int CinT, int splitK) {
     const int64_t total = (int64_t)Cout * taps * Cin;
@@ -372,10 +373,12 @@ int ssdhip_conv2d_wgrad(const ssdhip_wgrad_params* p, void* stream) {
     if (p->in_scale) hipLaunchKernelGGL(wgrad_kernel<true>, grid, block, 0, st, a);
     else hipLaunchKernelGGL(wgrad_kernel<false>, grid, block, 0, st, a);
     SSDHIP_CHECK_LAUNCH();
-    int64_t total = (int64_t)p->Cout * a.taps * p->Cin;
+    const int dw_cin = p->dw_cin > 0 ? p->dw_cin : p->Cin;
+    SSDHIP_REQUIRE(dw_cin <= p->Cin, "wgrad: dw_cin must not exceed Cin");
+    int64_t total = (int64_t)p->Cout * a.taps * dw_cin;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.ws, p->dw_oihw, p->Cout, p->Cin, a.taps, a.CoutT, a.CinT,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.ws, p->dw_oihw, p->Cout, dw_cin, a.taps, a.CoutT, a.CinT,
                        a.splitK);
     SSDHIP_CHECK_LAUNCH();
     if (p->dbias) {

@@ -6,7 +6,8 @@ Replaces the ATen dispatch behind SSD.forward (model/ssd.py:86-106) and the auto
     applied while layer L+1 (and its detector head) stage their input tiles, or fused into the max-pool pass;
   * BN batch statistics come from per-block partials written by the conv epilogue (no extra pass over `z`);
   * detector heads write straight into the (N, P, 4+C) output (zero-copy concat, ssd.py:103-104);
-  * the VGG part is frozen (ssd.py:31-32): no graph, no saved activations, no dgrad/wgrad for conv_1_1..conv_5_3;
+  * the VGG part is frozen (ssd.py:31-32): no graph, no saved activations, no dgrad/wgrad for conv_1_1..conv_5_3
+    (SSD.finetune_backbone() un-freezes it: the same backward loop then runs down to conv_1_1, through the max-pools);
   * gradients land in one flat fp32 buffer (views per parameter) so data-parallel all-reduce is a few large RCCL calls.
 """
 import ctypes
@@ -67,7 +68,7 @@ class Engine:
         while i < len(plan):
             l = plan[i]
             assert l['kind'] == 'conv'
-            conv = _ConvSpec(l['name'], l['cin'], l['cout'], l['k'], l['stride'], l['pad'], l['frozen'])
+            conv = _ConvSpec(l['name'], l['cin'], l['cout'], l['k'], l['stride'], l['pad'], l['frozen'] and not module._tune_all)
             bn = plan[i + 1]['name']
             i += 3
             pool_pad = None
@@ -367,12 +368,14 @@ class Engine:
         dev = b['x4'].device
         f = dict(device=dev, dtype=torch.float32)
         geo = b['geo']
-        bw = dict(da={}, dz={}, dyh={})
+        bw = dict(da={}, dz={}, dyh={}, dpool={})
         max_c, ws_bytes = 0, 0
         for i in range(self.tail_start, len(self.stages)):
             s, g = self.stages[i], geo[i]
             bw['da'][i] = torch.empty(N, g['ho'], g['wo'], s.conv.cout, **f)
             bw['dz'][i] = torch.empty(N, g['ho'], g['wo'], s.conv.cout, **f)
+            if s.pool_pad is not None:
+                bw['dpool'][i] = torch.empty(N, g['ha'], g['wa'], s.conv.cout, **f)
             max_c = max(max_c, s.conv.cout)
         for i, (s, g) in enumerate(zip(self.stages, geo)):
             if s.head is not None:
@@ -399,7 +402,8 @@ class Engine:
 
     def _wgrad_params(self, spec, N, hi, wi, ho, wo):
         p = _lib.WgradParams()
-        p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout = N, hi, wi, spec.cin, ho, wo, spec.cout
+        p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout = N, hi, wi, spec.cin_pad, ho, wo, spec.cout
+        p.dw_cin = spec.cin if spec.cin_pad != spec.cin else 0          # RGB input is padded to 4 channels, the parameter is not
         p.R, p.S, p.stride, p.pad = spec.k, spec.k, spec.stride, spec.pad
         p.dy_row = spec.co_pad if spec.is_head else spec.cout
         p.dy_batch_stride = ho * wo * p.dy_row
@@ -483,7 +487,7 @@ class Engine:
             _lib.check(L.ssdhip_bn_relu_bwd_apply(_lib.ptr(z), _lib.ptr(da), _lib.ptr(bst['scale']), _lib.ptr(bst['shift']),
                                                   _lib.ptr(bst['mean']), _lib.ptr(bst['invstd']), _lib.ptr(bw['coef']), M, c.cout,
                                                   _lib.ptr(dz), st), 'bn_relu_bwd_apply')
-            xin, xin_xs = acts[i - 1][2], acts[i - 1][3]
+            xin, xin_xs = (acts[i - 1][2], acts[i - 1][3]) if i > 0 else (b['x4'], None)
             if i == self.tail_start and self.dist_hook is not None:
                 # every gradient behind the first stage's parameters is final: reduce it while the largest wgrad runs
                 first = f'features.{c.name}.weight'
@@ -492,7 +496,15 @@ class Engine:
                 self.dist_hook.start(flat, cut, flat.numel())
             self._wgrad(c, xin, xin_xs, dz, views, bw, N, g['hi'], g['wi'], g['ho'], g['wo'])
             if i > self.tail_start:
-                self._dgrad(c, dz, bw['da'][i - 1], N, g['ho'], g['wo'], g['hi'], g['wi'], accumulate=False)
+                prev, gp = self.stages[i - 1], geo[i - 1]
+                if prev.pool_pad is None:
+                    self._dgrad(c, dz, bw['da'][i - 1], N, g['ho'], g['wo'], g['hi'], g['wi'], accumulate=False)
+                else:       # un-frozen backbone only: gradient of the pooled map, then through BN.ReLU.MaxPool to the pre-pool map
+                    self._dgrad(c, dz, bw['dpool'][i - 1], N, g['ho'], g['wo'], g['hi'], g['wi'], accumulate=False)
+                    pst = self._bn[prev.bn_name]
+                    _lib.check(L.ssdhip_bn_relu_pool_bwd(_lib.ptr(b['z'][i - 1]), _lib.ptr(pst['scale']), _lib.ptr(pst['shift']),
+                                                         _lib.ptr(bw['dpool'][i - 1]), _lib.ptr(bw['da'][i - 1]), N, gp['ho'], gp['wo'],
+                                                         prev.conv.cout, prev.pool_pad, st), f'pool backward after {prev.conv.name}')
         if self.dist_hook is not None:
             self.dist_hook.finish(flat)
         return [views[n] for n in names], params
