@@ -85,6 +85,9 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--imsize', type=int, choices=[300, 512], default=300,
                     help='300 = the reference network (headline); 512 = SSD512 extension (BASELINE configs[4] is its bf16 8-GPU form; run with --batch 16)')
+    ap.add_argument('--dtype', choices=['fp32', 'bf16'], default='fp32',
+                    help='fp32 = the headline (BASELINE configs[2]); bf16 = conv forward/dgrad on the bf16 MFMA with fp32 accumulate and fp32 master\n'
+                         'state (the single-GPU form of configs[3]); labelled, never the headline')
     ap.add_argument('--finetune-backbone', action='store_true',
                     help='extension (SURVEY 8(f)-4): un-freeze VGG16-bn (187.9 GFLOP/img instead of 72.2); never the headline')
     ap.add_argument('--mode', choices=['train', 'infer'], default='train',
@@ -106,6 +109,7 @@ def main():
     net = SSD(num_classes=21, imsize=args.imsize).to(dev)   # random-init weights (no pretrained weights offline)
     if args.finetune_backbone:
         net.finetune_backbone()
+    net.set_compute_dtype(args.dtype)
     df = net.default_bboxes.to(dev)
     world_n = parallel.attach(net) if world > 1 else 1
     opt = FusedAdam(net.train_params(), lr=1e-3, weight_decay=5e-4, grad_scale=1.0 / world_n, on_step=net.hip_weights_changed)
@@ -205,12 +209,16 @@ def main():
             line['metric'] = f'images/sec SSD{args.imsize} {"train step" if args.mode == "train" else "inference"}, batch {B}/GPU (extension variant, not the BASELINE metric)'
             line['config'].update(workload=f'SSD{args.imsize} {args.mode} batch={B}/GPU, fp32 ({P} priors; BASELINE configs[4] names its bf16 8-GPU form)',
                                   image=f'{args.imsize}x{args.imsize}x3', priors=P, gflop_per_image=round(gf_train if args.mode == 'train' else gf_fwd, 3))
+        if args.dtype == 'bf16':
+            line['dtype'] = 'bf16'
+            line['metric'] += ' (bf16 MFMA compute with fp32 accumulate / fp32 master state: BASELINE configs[3] form, not the fp32 headline)'
+            line['config']['precision'] = 'conv forward + data gradients: bf16 operands, fp32 accumulate; weights, activations in HBM, BN, weight gradients, loss, Adam: fp32'
         if args.finetune_backbone:
             line['metric'] += ' (extension: backbone un-frozen, not the BASELINE metric)'
             line['config'].update(backbone='VGG16-bn un-frozen (full fine-tuning)', gflop_per_image=round(gf_train, 3))
         if args.imsize == 300 and args.mode == 'infer':
             line['config']['workload'] = 'SSD300 inference batch=32, fp32, NMS on 8732 priors x 20 classes (BASELINE configs[1])'
-        if world == 1 and not args.no_cpu_baseline and args.mode == 'train' and args.imsize == 300 and not args.finetune_backbone:
+        if world == 1 and not args.no_cpu_baseline and args.mode == 'train' and args.imsize == 300 and not args.finetune_backbone and args.dtype == 'fp32':
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:

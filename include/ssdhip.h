@@ -75,6 +75,8 @@ typedef struct {
     int32_t tile;           /* 0 auto, else BM*1000+BN (128128, 128064, 064128, 064064)          */
     int32_t rows_per_img;   /* 0, or batched-GEMM use: output rows per weight plane (multiple of 128) */
     int64_t w_img_stride;   /* floats between consecutive weight planes (with rows_per_img)      */
+    int32_t compute;        /* 0: exact fp32 MFMA (default, the headline path); 1: operands rounded to bf16 at LDS staging,
+                               v_mfma_f32_32x32x16_bf16 with fp32 accumulate (BASELINE configs[3]); tensors stay fp32 in HBM */
 } ssdhip_conv_params;
 int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream);
 /* m-block size the auto/explicit tile choice will use for `stats` (rows of the partial table = ceil(M/BM)) */

@@ -17,6 +17,10 @@
 //   epilogue    + bias, NHWC store (each store instruction writes two full 128-B lines), optional per-(m-block,
 //               channel) partial sum / sum of squares for train-mode BatchNorm (deterministic: no atomics)
 //   tile order  XCD-aware: each XCD's L2 sees a contiguous run of m-tiles with all their n-tiles
+//   BF16 = true (BASELINE configs[3], opt-in; never the headline): the same gather / staging on the fp32 tensors, but the staged
+//               values are rounded to bf16 on the way into LDS (v_cvt_pk_bf16_f32; rows of 64 B, 16-B chunks XOR-swizzled with
+//               (row >> 2) & 3) and the products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulators (one ds_read_b128 = the
+//               8 k of one MFMA operand); epilogue, BN statistics and every tensor in HBM stay fp32
 #include "common.h"
 
 // gemm_planes.hip: LDS-DMA staged plane GEMM (Winograd domain)
@@ -26,6 +30,14 @@ int ssdhip_gemm_planes_dma(const float* v, const float* u, float* y, int M, int 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {      // round-to-nearest-even pair, lo in bits 0-15
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
 
 constexpr int BK = 32;
 constexpr int LDS_ROW = 32;  // floats per staged row: 128 B, no padding; 16-B chunks XOR-swizzled with (row >> 1) & 7
@@ -63,16 +75,17 @@ __device__ __forceinline__ void tap_rs(int tap, int& r, int& s) {
 template <int BM, int BN>
 struct ConvWaves { static constexpr int value = (BM + BN == 256) ? 2 : (BM + BN == 192) ? 3 : 4; };   // blocks per CU the LDS footprint admits
 
-template <int BM, int BN, int KS, int MODE, bool XFORM, bool SMALLC, int ABL = 0>
+template <int BM, int BN, int KS, int MODE, bool XFORM, bool SMALLC, int ABL = 0, bool BF16 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWaves<BM, BN>::value))) void conv_igemm_kernel(ConvArgs a) {
     constexpr int WROWS = BM / 2, WCOLS = BN / 2;     // per-wave output tile (wave grid 2 x 2)
     constexpr int MT = WROWS / 32, NT = WCOLS / 32;   // 32x32 MFMA tiles per wave
     constexpr int AL = BM / 32, BL = BN / 32;         // float4 loads per thread per stage (2 or 4)
     constexpr int GROUPS = 4 * MT * NT;               // groups of MFMAs per K-step (4 each; MT*NT each in element-major order)
     constexpr int SLICES = 17;                        // staging slices spread over the groups (see CONV_SLICE)
-    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_ROW];
+    constexpr int LROW = BF16 ? LDS_ROW / 2 : LDS_ROW;   // floats of LDS per staged row (bf16 rows are 64 B)
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LROW];
     float* As = lds;
-    float* Bs = lds + 2 * BM * LDS_ROW;
+    float* Bs = lds + 2 * BM * LROW;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -184,10 +197,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWave
             v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);                         \
         }                                                                                                             \
         if (!((okmask >> I) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f); /* zero padding AFTER the transform */        \
-        if (ABL != 2 || !in_loop) *reinterpret_cast<float4*>(Ast_ + 32 * I * LDS_ROW) = v;                            \
+        if (BF16) *reinterpret_cast<uint2*>(Ast_ + 32 * I * LROW) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w)); \
+        else if (ABL != 2 || !in_loop) *reinterpret_cast<float4*>(Ast_ + 32 * I * LROW) = v;                          \
         else asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));                                              \
     }
-#define CONV_STORE_B(I) if (BL > I) { if (ABL != 2 || !in_loop) *reinterpret_cast<float4*>(Bst_ + 32 * I * LDS_ROW) = rb##I; else asm volatile("" :: "v"(rb##I.x), "v"(rb##I.y), "v"(rb##I.z), "v"(rb##I.w)); }
+#define CONV_STORE_B(I) if (BL > I) { if (BF16) *reinterpret_cast<uint2*>(Bst_ + 32 * I * LROW) = make_uint2(pack_bf16(rb##I.x, rb##I.y), pack_bf16(rb##I.z, rb##I.w)); else if (ABL != 2 || !in_loop) *reinterpret_cast<float4*>(Bst_ + 32 * I * LROW) = rb##I; else asm volatile("" :: "v"(rb##I.x), "v"(rb##I.y), "v"(rb##I.z), "v"(rb##I.w)); }
     // slice N of the staging work of one K-step: 0-7 write tile kt+1 (registers) to LDS, 8 advances the loader,
     // 9-16 issue the global loads of tile kt+2 into the same registers.  N is a constant after unrolling.
 #define CONV_SLICE(N)                                                                                                 \
@@ -220,9 +234,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWave
     // the matrix pipe's shadow.  sched_barrier(0) pins the group/slice order; one barrier per K-step.
     // LDS image: row r, logical 16-B chunk q lives at chunk q ^ ((r >> 1) & 7): rows r and r+32 share the swizzle, and any
     // 16 rows of a ds_read_b128 lane group cover all 16 slots of the 256-B bank row (conflict-free without padding)
-    const int st_chunk = (col4 ^ ((lrow >> 1) & 7)) * 4;
-    float* Ast_ = As + lrow * LDS_ROW + st_chunk;
-    float* Bst_ = Bs + lrow * LDS_ROW + st_chunk;
+    // bf16 image: row r, logical 16-B chunk q (8 k) at chunk q ^ ((r >> 2) & 3); a lane's 4 k are one 8-B half of a chunk
+    const int st_chunk = BF16 ? ((col4 >> 1) ^ ((lrow >> 2) & 3)) * 4 + (col4 & 1) * 2 : (col4 ^ ((lrow >> 1) & 7)) * 4;
+    float* Ast_ = As + lrow * LROW + st_chunk;
+    float* Bst_ = Bs + lrow * LROW + st_chunk;
     bool in_loop = false;
     CONV_LOAD_ALL()          // tile 0
     CONV_STORE_ALL()
@@ -234,29 +249,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWave
     int fko[4];                      // float offset of k-chunk kc for this lane: logical chunk 2*kc + fh, swizzled
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc) fko[kc] = ((2 * kc + fh) ^ fx) * 4;
-    const float* Afr = As + (wm * WROWS + frow) * LDS_ROW;
-    const float* Bfr = Bs + (wn * WCOLS + frow) * LDS_ROW;
+    const float* Afr = As + (wm * WROWS + frow) * LROW;
+    const float* Bfr = Bs + (wn * WCOLS + frow) * LROW;
+    const int fko8[2] = {((0 + fh) ^ ((frow >> 2) & 3)) * 4, ((2 + fh) ^ ((frow >> 2) & 3)) * 4};   // bf16: chunk 2 m + fh of MFMA m
     const int total_steps = ntl * a.KT;
     int kt_in = 0, m_cur = m0;             // K-step inside the current m-tile, first row of that tile
     for (int kt = 0; kt < total_steps; ++kt) {
         const int buf = kt & 1;
-        Ast_ = As + (buf ^ 1) * BM * LDS_ROW + lrow * LDS_ROW + st_chunk;
-        Bst_ = Bs + (buf ^ 1) * BN * LDS_ROW + lrow * LDS_ROW + st_chunk;
-        const float* Ab = Afr + buf * BM * LDS_ROW;
-        const float* Bb = Bfr + buf * BN * LDS_ROW;
+        Ast_ = As + (buf ^ 1) * BM * LROW + lrow * LROW + st_chunk;
+        Bst_ = Bs + (buf ^ 1) * BN * LROW + lrow * LROW + st_chunk;
+        const float* Ab = Afr + buf * BM * LROW;
+        const float* Bb = Bfr + buf * BN * LROW;
+        if constexpr (BF16) {
+            // 2 MFMAs of K = 16 per output tile and K-step; the staging slices go behind each half's MT*NT MFMAs
+            bf16x8 ha[2][MT], hb[2][NT];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) ha[m][i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * LROW + fko8[m]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) hb[m][j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * LROW + fko8[m]);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[m][i], hb[m][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int sl = 0; sl < SLICES; ++sl)
+                    if (sl >= m * 9 && sl < (m + 1) * 9) { CONV_SLICE(sl) }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
         float4 fa[2][MT], fb[2][NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) fa[0][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_ROW + fko[0]);
+        for (int i = 0; i < MT; ++i) fa[0][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LROW + fko[0]);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) fb[0][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_ROW + fko[0]);
+        for (int j = 0; j < NT; ++j) fb[0][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LROW + fko[0]);
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
             const int cur = kc & 1;
             if (kc < 3) {      // fragments of the next k-chunk, in flight under this chunk's MFMAs
 #pragma unroll
-                for (int i = 0; i < MT; ++i) fa[cur ^ 1][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_ROW + fko[kc < 3 ? kc + 1 : 0]);
+                for (int i = 0; i < MT; ++i) fa[cur ^ 1][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LROW + fko[kc < 3 ? kc + 1 : 0]);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) fb[cur ^ 1][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_ROW + fko[kc < 3 ? kc + 1 : 0]);
+                for (int j = 0; j < NT; ++j) fb[cur ^ 1][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LROW + fko[kc < 3 ? kc + 1 : 0]);
             }
             // element-major order: consecutive MFMAs hit different accumulators, so a staging instruction slipped between
             // them never sits on a dependent-accumulator chain (64-cycle latency == issue interval leaves no slack)
@@ -278,6 +316,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWave
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+        }
         }
         if (a.tpb > 1) {           // persistent plane-GEMM: a finished m-tile is stored from inside the pipeline (dense rows)
             if (++kt_in == a.KT) {
@@ -410,9 +449,16 @@ int choose_tile(const ssdhip_conv_params* p, int& BM, int& BN) {
 }
 
 template <int BM, int BN, int KS>
-void launch_conv(const ConvArgs& a, int mode, bool xform, hipStream_t st) {
+void launch_conv(const ConvArgs& a, int mode, bool xform, bool bf16, hipStream_t st) {
     dim3 grid(cdiv(a.MB, a.tpb) * a.NB), block(256);
-    if (a.Cin == 4) {
+    if (bf16) {          // never the padded-RGB layer, never a plane GEMM (checked by the caller)
+        if (mode == 0) {
+            if (xform) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, KS, 0, true, false, 0, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, KS, 0, false, false, 0, true>), grid, block, 0, st, a);
+        } else {
+            hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, KS, 1, false, false, 0, true>), grid, block, 0, st, a);
+        }
+    } else if (a.Cin == 4) {
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, KS, 0, false, true>), grid, block, 0, st, a);
     } else if (mode == 0) {
         if (xform) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, KS, 0, true, false>), grid, block, 0, st, a);
@@ -455,6 +501,9 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
         SSDHIP_REQUIRE(p->Ho == (p->Hi + 2 * p->pad - p->R) / p->stride + 1 && p->Wo == (p->Wi + 2 * p->pad - p->S) / p->stride + 1,
                        "conv2d: output size does not match input/stride/pad");
     }
+    SSDHIP_REQUIRE(p->compute == 0 || p->compute == 1, "conv2d: compute 0 (fp32 MFMA) or 1 (bf16 MFMA, fp32 accumulate)");
+    const bool bf16 = p->compute == 1;
+    SSDHIP_REQUIRE(!bf16 || (p->Cin != 4 && p->rows_per_img == 0 && p->tile < 1000000), "conv2d: bf16 compute is for the plain conv layers");
     int BM, BN;
     SSDHIP_REQUIRE(choose_tile(p, BM, BN) == SSDHIP_OK, "conv2d: tile must be one of 128128/128064/64128/64064");
     SSDHIP_REQUIRE(p->rows_per_img == 0 || (p->rows_per_img % BM == 0 && p->mode == 0 && p->w_img_stride > 0),
@@ -502,8 +551,8 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
     const int key = BM * 1000 + BN;
 #define SSDHIP_CONV_CASE(bm, bn)                                            \
     case bm * 1000 + bn:                                                    \
-        if (p->R == 3) launch_conv<bm, bn, 3>(a, p->mode, xf, st);          \
-        else launch_conv<bm, bn, 1>(a, p->mode, xf, st);                    \
+        if (p->R == 3) launch_conv<bm, bn, 3>(a, p->mode, xf, bf16, st);    \
+        else launch_conv<bm, bn, 1>(a, p->mode, xf, bf16, st);              \
         break;
     // stride-2 data gradient: one launch per output-parity class, each with only the taps that land on a dy pixel
     // (tiny layers stay on one masked launch: four launches cost more than the wasted MFMAs; measured at M = 3200)

@@ -87,6 +87,7 @@ class Engine:
         self._saved = None     # forward context consumed by backward
         self._flat = None
         self.dist_hook = None  # callable(flat_grad) for data-parallel all-reduce (parallel.py)
+        self.bf16 = False      # set per forward from module.compute_dtype; backward follows the saved forward
         self.prof = None       # list: when set, forward conv launches are bracketed by events (bench.py roofline leg)
 
     # ------------------------------------------------------------------------------------------------ helpers
@@ -263,6 +264,7 @@ class Engine:
         p.Ho, p.Wo, p.Cout = ho, wo, spec.cout
         p.R, p.S, p.stride, p.pad = spec.k, spec.k, spec.stride, spec.pad
         p.KP, p.mode, p.accumulate, p.tile = spec.KP, 0, 0, tile
+        p.compute = int(self.bf16 and spec.cin_pad != 4)      # the padded-RGB layer (K = 27) stays on the fp32 kernel
         bm = self.lib.ssdhip_conv2d_block_m(ctypes.byref(p))
         if self.prof is None:
             _lib.check(self.lib.ssdhip_conv2d_nhwc(ctypes.byref(p), _lib.stream()), f'conv2d {spec.name}')
@@ -273,9 +275,10 @@ class Engine:
         e1.record()
         tile = self.lib.ssdhip_conv2d_tile(ctypes.byref(p))
         # the symbol rocprofv3 reports for this launch (template arguments BM, BN, KS, MODE, XFORM, SMALLC, ABL)
-        kernel = 'conv_igemm_kernel<%d, %d, %d, 0, %s, %s, 0>' % (tile // 1000, tile % 1000, spec.k,
-                                                                  'true' if xs is not None else 'false',
-                                                                  'true' if spec.cin_pad == 4 else 'false')
+        kernel = 'conv_igemm_kernel<%d, %d, %d, 0, %s, %s, 0%s>' % (tile // 1000, tile % 1000, spec.k,
+                                                                    'true' if xs is not None else 'false',
+                                                                    'true' if spec.cin_pad == 4 else 'false',
+                                                                    ', true' if p.compute else '')
         self.prof.append(dict(layer=spec.name, kernel=kernel, flops=2.0 * N * ho * wo * spec.cout * spec.cin * spec.k * spec.k,
                               e0=e0, e1=e1))
         return bm
@@ -291,6 +294,7 @@ class Engine:
         b = self._buffers(N, H, W, dev)
         geo = b['geo']
         training = self.m.training
+        self.bf16 = self.m.compute_dtype == 'bf16'
         out = torch.empty(N, b['P'], self.row, device=dev, dtype=torch.float32)
         st = _lib.stream()
         _lib.check(self.lib.ssdhip_normalize_nchw_to_nhwc4(_lib.ptr(x), _lib.ptr(b['x4']), N, H, W, st), 'normalize')
@@ -303,7 +307,7 @@ class Engine:
             z = b['z'][i]
             M = N * g['ho'] * g['wo']
             bst = self._bn_state(s.bn_name, c.cout, dev)
-            if c.wino and self._wino_ok(g):
+            if c.wino and self._wino_ok(g) and not self.bf16:     # bf16 MFMA outruns the fp32 Winograd pipeline: direct kernel
                 rows = self._conv_winograd(c, cur, cur_xs, z, b, N, g['hi'], g['wi'], b['partial'] if training else None)
             else:
                 bm = self._conv(c, cur, cur_xs, z.data_ptr(), g['ho'] * g['wo'] * c.cout, N, g['hi'], g['wi'], g['ho'], g['wo'],
@@ -334,7 +338,7 @@ class Engine:
             acts.append((z, act_xs, cur, cur_xs))
             if s.head is not None:
                 off = b['head_off'][s.head_index]
-                if i in b['head_v']:
+                if i in b['head_v'] and not self.bf16:
                     self._head_winograd(s.head, z, act_xs, b['head_v'][i], b, ctypes.c_void_p(out.data_ptr() + off * self.row * 4),
                                         b['P'] * self.row, N, g['ho'], g['wo'])
                 else:
@@ -342,7 +346,7 @@ class Engine:
                                g['ho'], g['wo'], None)
         if nbt:
             torch._foreach_add_(nbt, 1)
-        self._saved = dict(b=b, N=N, acts=acts, training=training) if save else None
+        self._saved = dict(b=b, N=N, acts=acts, training=training, bf16=self.bf16) if save else None
         return out
 
     # ------------------------------------------------------------------------------------------------ backward
@@ -433,6 +437,7 @@ class Engine:
         p.Ho, p.Wo, p.Cout = hin, win, spec.cin
         p.R, p.S, p.stride, p.pad = spec.k, spec.k, spec.stride, spec.pad
         p.KP, p.mode, p.accumulate, p.tile = spec.KPd, 1, int(accumulate), 0
+        p.compute = int(self.bf16)
         _lib.check(self.lib.ssdhip_conv2d_nhwc(ctypes.byref(p), _lib.stream()), f'dgrad {spec.name}')
 
     def backward(self, grad_out):
@@ -442,6 +447,7 @@ class Engine:
         if not sv['training']:
             raise RuntimeError('backward through eval-mode BatchNorm is not implemented (the reference never calls eval())')
         self._saved = None
+        self.bf16 = sv['bf16']
         b, N, acts = sv['b'], sv['N'], sv['acts']
         geo = b['geo']
         _lib.require_gpu(grad_out)
@@ -462,7 +468,7 @@ class Engine:
             s, g = self.stages[i], geo[i]
             if s.head is not None:
                 x, xs = acts[i][0], acts[i][1]
-                self._wgrad(s.head, x, xs, bw['dyh'][i], views, bw, N, g['ho'], g['wo'], g['ho'], g['wo'], b['head_v'].get(i))
+                self._wgrad(s.head, x, xs, bw['dyh'][i], views, bw, N, g['ho'], g['wo'], g['ho'], g['wo'], None if self.bf16 else b['head_v'].get(i))
         last = len(self.stages) - 1
         for i in range(last, self.tail_start - 1, -1):
             s, g = self.stages[i], geo[i]
@@ -470,7 +476,7 @@ class Engine:
             da, dz = bw['da'][i], bw['dz'][i]
             x_act, x_xs = acts[i][0], acts[i][1]        # this stage's activation (input of its head)
             if s.head is not None:
-                self._wgrad(s.head, x_act, x_xs, bw['dyh'][i], views, bw, N, g['ho'], g['wo'], g['ho'], g['wo'], b['head_v'].get(i))
+                self._wgrad(s.head, x_act, x_xs, bw['dyh'][i], views, bw, N, g['ho'], g['wo'], g['ho'], g['wo'], None if self.bf16 else b['head_v'].get(i))
                 self._dgrad(s.head, bw['dyh'][i], da, N, g['ho'], g['wo'], g['ho'], g['wo'], accumulate=(i != last))
             # BatchNorm(train) + ReLU backward: da -> dz, d gamma, d beta
             bst = self._bn[s.bn_name]

@@ -94,6 +94,7 @@ class SSD(nn.Module):
         self._hip_epoch = 0
         self._eng = None
         self._tune_all = False
+        self.compute_dtype = 'fp32'      # 'bf16': see set_compute_dtype
         self._engine_token = None
         self._default_bboxes = None      # generated lazily by the HIP kernel (first access needs the GPU)
 
@@ -214,6 +215,15 @@ class SSD(nn.Module):
                 for p in layer.parameters():
                     p.requires_grad = self._tune_all
         self._eng = None            # new launch plan: frozen flags, gradient layout, backward depth
+        return self
+
+    def set_compute_dtype(self, dtype: str):
+        """'fp32' (default; exact-fp32 MFMA, Winograd for the deep 3x3 layers) or 'bf16' (BASELINE configs[3]: conv forward and
+        data gradients on the bf16 MFMA with fp32 accumulation, operands rounded while staged; parameters, activations,
+        BN statistics, weight gradients, loss and Adam stay fp32 = the "fp32 master" side)."""
+        if dtype not in ('fp32', 'bf16'):
+            raise ValueError(f"compute dtype must be 'fp32' or 'bf16', got {dtype!r}")
+        self.compute_dtype = dtype
         return self
 
     def named_train_params(self):

@@ -29,8 +29,9 @@ def pack_weight(w_oihw, mode=0):
     return packed, KP, inner
 
 
-def conv2d_nhwc(x, w_oihw, bias=None, stride=1, pad=0, in_scale=None, in_shift=None, want_stats=False, tile=0):
-    """x (N,H,W,Cin_pad) fp32 NHWC -> (z (N,Ho,Wo,Cout), stats or None).  stats: (MB, Cout, 2) partial sums."""
+def conv2d_nhwc(x, w_oihw, bias=None, stride=1, pad=0, in_scale=None, in_shift=None, want_stats=False, tile=0, bf16=False):
+    """x (N,H,W,Cin_pad) fp32 NHWC -> (z (N,Ho,Wo,Cout), stats or None).  stats: (MB, Cout, 2) partial sums.
+    bf16: operands rounded to bf16 at staging, bf16 MFMA with fp32 accumulate (tensors stay fp32)."""
     _lib.require_gpu(x, w_oihw)
     lib = _lib.load()
     N, H, W, C = x.shape
@@ -47,6 +48,7 @@ def conv2d_nhwc(x, w_oihw, bias=None, stride=1, pad=0, in_scale=None, in_shift=N
     p.y, p.y_batch_stride = z.data_ptr(), ho * wo * cout
     p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout = N, H, W, C, ho, wo, cout
     p.R, p.S, p.stride, p.pad, p.KP, p.mode, p.accumulate, p.tile = k, k, stride, pad, KP, 0, 0, tile
+    p.compute = int(bool(bf16))
     stats = None
     if want_stats:
         bm = lib.ssdhip_conv2d_block_m(ctypes.byref(p))
@@ -56,7 +58,7 @@ def conv2d_nhwc(x, w_oihw, bias=None, stride=1, pad=0, in_scale=None, in_shift=N
     return z, stats
 
 
-def conv2d_dgrad(dy, w_oihw, in_hw, stride=1, pad=0, accumulate_into=None, tile=0):
+def conv2d_dgrad(dy, w_oihw, in_hw, stride=1, pad=0, accumulate_into=None, tile=0, bf16=False):
     """dy (N,Ho,Wo,Cout_pad) -> dx (N,Hi,Wi,Cin): data gradient of conv2d(x, w, stride, pad)."""
     _lib.require_gpu(dy, w_oihw)
     N, ho, wo, cdy = dy.shape
@@ -70,6 +72,7 @@ def conv2d_dgrad(dy, w_oihw, in_hw, stride=1, pad=0, accumulate_into=None, tile=
     p.x, p.w, p.y, p.y_batch_stride = dy.data_ptr(), packed.data_ptr(), dx.data_ptr(), hi * wi * cin
     p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout = N, ho, wo, cdy, hi, wi, cin
     p.R, p.S, p.stride, p.pad, p.KP, p.mode, p.accumulate, p.tile = k, k, stride, pad, KP, 1, int(accumulate_into is not None), tile
+    p.compute = int(bool(bf16))
     _lib.check(_lib.load().ssdhip_conv2d_nhwc(ctypes.byref(p), _lib.stream()), 'conv2d_dgrad')
     return dx
 
