@@ -25,10 +25,24 @@ def test_library_exports_every_declared_symbol():
     assert _lib.load().ssdhip_version() >= 100
 
 
-def test_struct_layout_matches_header():
-    # the ctypes mirrors must have the C layout the header declares (8 pointers/int64 then int32s)
-    assert ctypes.sizeof(_lib.ConvParams) == 8 * 8 + 16 * 4 + 8
-    assert ctypes.sizeof(_lib.WgradParams) == 8 * 8 + 12 * 4 + 4 + 4 + 8
+def test_struct_layout_matches_header(tmp_path):
+    """The ctypes mirrors must have the C layout include/ssdhip.h declares: ask the C compiler for size and field offsets."""
+    import subprocess
+    fields = {'ssdhip_conv_params': (_lib.ConvParams, ['x', 'y_batch_stride', 'N', 'KP', 'tile', 'rows_per_img', 'w_img_stride', 'compute']),
+              'ssdhip_wgrad_params': (_lib.WgradParams, ['x', 'ws', 'dy_batch_stride', 'N', 'pad', 'dy_row', 'dw_cin', 'wino_v'])}
+    prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT}/include/ssdhip.h"', 'int main(void) {']
+    for t, (_, names) in fields.items():
+        prog.append(f'printf("%zu", sizeof({t}));')
+        prog += [f'printf(" %zu", offsetof({t}, {n}));' for n in names]
+        prog.append('printf("\\n");')
+    prog.append('return 0; }')
+    (tmp_path / 'layout.c').write_text('\n'.join(prog))
+    subprocess.run(['gcc', str(tmp_path / 'layout.c'), '-o', str(tmp_path / 'layout')], check=True)
+    lines = subprocess.run([str(tmp_path / 'layout')], check=True, capture_output=True, text=True).stdout.strip().split('\n')
+    for line, (t, (cls, names)) in zip(lines, fields.items()):
+        want = [int(v) for v in line.split()]
+        got = [ctypes.sizeof(cls)] + [getattr(cls, n).offset for n in names]
+        assert got == want, (t, got, want)
 
 
 def test_module_surface_matches_reference_contract():
