@@ -8,9 +8,13 @@ Replaces the ATen dispatch behind SSD.forward (model/ssd.py:86-106) and the auto
   * detector heads write straight into the (N, P, 4+C) output (zero-copy concat, ssd.py:103-104);
   * the VGG part is frozen (ssd.py:31-32): no graph, no saved activations, no dgrad/wgrad for conv_1_1..conv_5_3
     (SSD.finetune_backbone() un-freezes it: the same backward loop then runs down to conv_1_1, through the max-pools);
-  * gradients land in one flat fp32 buffer (views per parameter) so data-parallel all-reduce is a few large RCCL calls.
+  * gradients land in one flat fp32 buffer (views per parameter) so data-parallel all-reduce is a few large RCCL calls;
+  * two HIP streams: the detector heads (forward) and every weight gradient (backward) run on a side stream next to the
+    layer chain -- the small late-stage launches cannot fill 256 CUs one at a time (SSD_SINGLE_STREAM=1 disables it).
 """
+import contextlib
 import ctypes
+import os
 
 import torch
 
@@ -87,6 +91,8 @@ class Engine:
         self._saved = None     # forward context consumed by backward
         self._flat = None
         self.dist_hook = None  # callable(flat_grad) for data-parallel all-reduce (parallel.py)
+        self._side = {}        # device -> side stream (heads / weight gradients)
+        self.single_stream = os.environ.get('SSD_SINGLE_STREAM', '0') == '1'
         self.bf16 = False      # set per forward from module.compute_dtype; backward follows the saved forward
         self.prof = None       # list: when set, forward conv launches are bracketed by events (bench.py roofline leg)
 
@@ -167,13 +173,15 @@ class Engine:
                 tp = (N * ((g['hi'] + 1) // 2) * ((g['wi'] + 1) // 2) + 127) // 128 * 128
                 wino_v, wino_m = max(wino_v, 16 * tp * s.conv.cin), max(wino_m, 16 * tp * s.conv.cout)
         b['head_v'] = {}
+        head_m = 0
         for i, (s, g) in enumerate(zip(self.stages, geo)):
             if s.head is not None and s.head.wino_head and min(g['ho'], g['wo']) >= 10:
                 tp = (N * ((g['ho'] + 1) // 2) * ((g['wo'] + 1) // 2) + 127) // 128 * 128
                 b['head_v'][i] = torch.empty(16 * tp * s.head.cin, **f)
-                wino_m = max(wino_m, 16 * tp * s.head.co_pad)
+                head_m = max(head_m, 16 * tp * s.head.co_pad)     # own workspace: the heads run on the side stream
         b['wino_v'] = torch.empty(wino_v, **f) if wino_v else None
         b['wino_m'] = torch.empty(wino_m, **f) if wino_m else None
+        b['head_m'] = torch.empty(head_m, **f) if head_m else None
         b['partial'] = torch.empty(max_partial, **f)
         b['ws64'] = torch.empty(64 * cmax * 2, device=dev, dtype=torch.float64)
         if len(self._bufs) >= 3:                 # keep the three most recent batch geometries (≈3.4 GB each at N=32)
@@ -235,7 +243,7 @@ class Engine:
         L, st = self.lib, _lib.stream()
         U = self._wino_weights(spec)
         _, bias = self._weight(spec)
-        Mo = b['wino_m']
+        Mo = b['head_m']
         tp = (N * ((h + 1) // 2) * ((w + 1) // 2) + 127) // 128 * 128
         _lib.check(L.ssdhip_winograd_input(_lib.ptr(x), _lib.ptr(xs[0]) if xs is not None else None,
                                            _lib.ptr(xs[1]) if xs is not None else None, _lib.ptr(V), N, h, w, spec.cin, st), f'winograd_input {spec.name}')
@@ -283,6 +291,40 @@ class Engine:
                               e0=e0, e1=e1))
         return bm
 
+    # ------------------------------------------------------------------------------------------------ streams
+    def _side_stream(self, dev, which=0):
+        st = self._side.get((dev, which))
+        if st is None:
+            st = torch.cuda.Stream(device=dev)
+            self._side[(dev, which)] = st
+        return st
+
+    class _Fork:
+        """`with fork.side():` enqueues on the side stream after everything the main stream has enqueued so far;
+        `fork.join()` makes the main stream wait for the side stream.  No-op object when single_stream is set."""
+
+        def __init__(self, engine, dev, which=0):
+            self.main = torch.cuda.current_stream(dev)
+            self.side_stream = None if engine.single_stream else engine._side_stream(dev, which)
+
+        def side(self):
+            if self.side_stream is None:
+                return contextlib.nullcontext()
+            self.side_stream.wait_event(self.main.record_event())
+            return torch.cuda.stream(self.side_stream)
+
+        def join(self):
+            if self.side_stream is not None:
+                self.main.wait_event(self.side_stream.record_event())
+
+        def mark(self):
+            """Event at the side stream's current tail (None when single-stream)."""
+            return self.side_stream.record_event() if self.side_stream is not None else None
+
+        def wait(self, event):
+            if event is not None:
+                self.main.wait_event(event)
+
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, x, save):
         _lib.require_gpu(x)
@@ -301,9 +343,29 @@ class Engine:
         cur, cur_xs = b['x4'], None
         acts = []            # per stage: (z, xform) read by its head, (tensor, xform) read by the next conv
         nbt = []
+        fork = self._Fork(self, dev)
+        if save and self.tail_start > 0:
+            # the optimizer just changed every trainable weight: repack them (forward + data-gradient layouts, Winograd U) on the
+            # side stream while the frozen backbone runs; the later _pack / _wino_weights calls find their keys current
+            with fork.side():
+                for i, (s, g) in enumerate(zip(self.stages, geo)):       # includes det_4_3 on the frozen conv_4_3
+                    for spec in (s.conv, s.head):
+                        if spec is None or spec.frozen:
+                            continue
+                        if not self.bf16 and ((spec.wino and self._wino_ok(g)) or (spec.is_head and i in b['head_v'])):
+                            self._wino_weights(spec)
+                        else:
+                            self._pack(spec)
+                        if i > self.tail_start or spec.is_head and i >= self.tail_start:
+                            self._pack(spec, dgrad=True)
+            prepacked = fork.mark()
+        else:
+            prepacked = None
         for i, (s, g) in enumerate(zip(self.stages, geo)):
             c = s.conv
             bnm = self.m.features[s.bn_name]
+            if i == self.tail_start:
+                fork.wait(prepacked)
             z = b['z'][i]
             M = N * g['ho'] * g['wo']
             bst = self._bn_state(s.bn_name, c.cout, dev)
@@ -338,12 +400,14 @@ class Engine:
             acts.append((z, act_xs, cur, cur_xs))
             if s.head is not None:
                 off = b['head_off'][s.head_index]
-                if i in b['head_v'] and not self.bf16:
-                    self._head_winograd(s.head, z, act_xs, b['head_v'][i], b, ctypes.c_void_p(out.data_ptr() + off * self.row * 4),
-                                        b['P'] * self.row, N, g['ho'], g['wo'])
-                else:
-                    self._conv(s.head, z, act_xs, out.data_ptr() + off * self.row * 4, b['P'] * self.row, N, g['ho'], g['wo'],
-                               g['ho'], g['wo'], None)
+                with fork.side():            # needs z and this stage's BN scale/shift only; writes its own rows of `out`
+                    if i in b['head_v'] and not self.bf16:
+                        self._head_winograd(s.head, z, act_xs, b['head_v'][i], b, ctypes.c_void_p(out.data_ptr() + off * self.row * 4),
+                                            b['P'] * self.row, N, g['ho'], g['wo'])
+                    else:
+                        self._conv(s.head, z, act_xs, out.data_ptr() + off * self.row * 4, b['P'] * self.row, N, g['ho'], g['wo'],
+                                   g['ho'], g['wo'], None)
+        fork.join()
         if nbt:
             torch._foreach_add_(nbt, 1)
         self._saved = dict(b=b, N=N, acts=acts, training=training, bf16=self.bf16) if save else None
@@ -463,12 +527,16 @@ class Engine:
                 _lib.check(L.ssdhip_scatter_head_grad(_lib.ptr(grad_out), _lib.ptr(bw['dyh'][i]), N, b['P'], self.row,
                                                       b['head_off'][s.head_index], g['ho'] * g['wo'], s.head.cout, s.head.co_pad, st),
                            'scatter_head_grad')
+        # Weight gradients are leaves of the dependency graph (nothing downstream reads them before the optimizer): they all go
+        # to the side stream, each after the main stream has produced its dy, and run next to the BN / data-gradient chain.
+        fork = self._Fork(self, dev)
         # heads on frozen activations (det_4_3): weight gradient only
         for i in range(self.tail_start):
             s, g = self.stages[i], geo[i]
             if s.head is not None:
                 x, xs = acts[i][0], acts[i][1]
-                self._wgrad(s.head, x, xs, bw['dyh'][i], views, bw, N, g['ho'], g['wo'], g['ho'], g['wo'], None if self.bf16 else b['head_v'].get(i))
+                with fork.side():
+                    self._wgrad(s.head, x, xs, bw['dyh'][i], views, bw, N, g['ho'], g['wo'], g['ho'], g['wo'], None if self.bf16 else b['head_v'].get(i))
         last = len(self.stages) - 1
         for i in range(last, self.tail_start - 1, -1):
             s, g = self.stages[i], geo[i]
@@ -476,7 +544,8 @@ class Engine:
             da, dz = bw['da'][i], bw['dz'][i]
             x_act, x_xs = acts[i][0], acts[i][1]        # this stage's activation (input of its head)
             if s.head is not None:
-                self._wgrad(s.head, x_act, x_xs, bw['dyh'][i], views, bw, N, g['ho'], g['wo'], g['ho'], g['wo'], None if self.bf16 else b['head_v'].get(i))
+                with fork.side():
+                    self._wgrad(s.head, x_act, x_xs, bw['dyh'][i], views, bw, N, g['ho'], g['wo'], g['ho'], g['wo'], None if self.bf16 else b['head_v'].get(i))
                 self._dgrad(s.head, bw['dyh'][i], da, N, g['ho'], g['wo'], g['ho'], g['wo'], accumulate=(i != last))
             # BatchNorm(train) + ReLU backward: da -> dz, d gamma, d beta
             bst = self._bn[s.bn_name]
@@ -499,8 +568,10 @@ class Engine:
                 first = f'features.{c.name}.weight'
                 cut = self._flat['offs'][names.index(f'features.{self.stages[i + 1].conv.name}.weight')]
                 assert self._flat['offs'][names.index(first)] == 0
+                fork.join()
                 self.dist_hook.start(flat, cut, flat.numel())
-            self._wgrad(c, xin, xin_xs, dz, views, bw, N, g['hi'], g['wi'], g['ho'], g['wo'])
+            with fork.side():
+                self._wgrad(c, xin, xin_xs, dz, views, bw, N, g['hi'], g['wi'], g['ho'], g['wo'])
             if i > self.tail_start:
                 prev, gp = self.stages[i - 1], geo[i - 1]
                 if prev.pool_pad is None:
@@ -511,6 +582,7 @@ class Engine:
                     _lib.check(L.ssdhip_bn_relu_pool_bwd(_lib.ptr(b['z'][i - 1]), _lib.ptr(pst['scale']), _lib.ptr(pst['shift']),
                                                          _lib.ptr(bw['dpool'][i - 1]), _lib.ptr(bw['da'][i - 1]), N, gp['ho'], gp['wo'],
                                                          prev.conv.cout, prev.pool_pad, st), f'pool backward after {prev.conv.name}')
+        fork.join()
         if self.dist_hook is not None:
             self.dist_hook.finish(flat)
         return [views[n] for n in names], params
