@@ -232,7 +232,7 @@ class Engine:
             e1.record()
             self.prof.append(dict(layer=spec.name + ' (winograd-domain GEMM)',
                                   # K >= 256 planes are staged by the LDS-DMA kernel (gemm_planes.hip), K = 128 by the register-staged one
-                                  kernel=('gemm_planes_dma_kernel<%d, 128>' if spec.cin >= 256 else 'conv_igemm_kernel<%d, 128, 1, 0, false, false, 0>') % (p.tile // 1000),
+                                  kernel=('gemm_planes_dma_kernel<%d, 128, 0>' if spec.cin >= 256 else 'conv_igemm_kernel<%d, 128, 1, 0, false, false, 0, false>') % (p.tile // 1000),
                                   direct_flops=2.0 * N * h * w * spec.cin * spec.cout * 9,
                                   flops=2.0 * 16 * tp * spec.cin * spec.cout, e0=e0, e1=e1))
         return _lib.check(L.ssdhip_winograd_output(_lib.ptr(Mo), _lib.ptr(bias), _lib.ptr(z), _lib.ptr(stats), N, h, w, spec.cout, st),
@@ -288,7 +288,7 @@ class Engine:
         kernel = 'conv_igemm_kernel<%d, %d, %d, 0, %s, %s, 0%s>' % (tile // 1000, tile % 1000, spec.k,
                                                                     'true' if xs is not None else 'false',
                                                                     'true' if spec.cin_pad == 4 else 'false',
-                                                                    ', true' if p.compute else '')
+                                                                    ', true' if p.compute else ', false')
         self.prof.append(dict(layer=spec.name, kernel=kernel, flops=2.0 * N * ho * wo * spec.cout * spec.cin * spec.k * spec.k,
                               e0=e0, e1=e1))
         return bm
