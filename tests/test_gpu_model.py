@@ -225,3 +225,27 @@ def test_fused_adam_checkpoint_resume(env):
     assert l0 == l1
     for (k, a), (_, b) in zip(nets[0].state_dict().items(), nets[1].state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_training_reduces_the_loss_on_a_fixed_batch(env):
+    """Size-independent property of the whole step (forward, mining, backward, Adam) at the headline batch size: 25 steps on
+    one fixed batch of 32 drive the MultiBox loss down monotonically in trend (it cannot if any gradient has the wrong sign
+    or scale); running statistics and every parameter stay finite."""
+    from object_detection_torch2_amd.optim import FusedAdam
+    synth = env['synth']
+    net = make_net(env)
+    opt = FusedAdam(net.train_params(), lr=1e-3, weight_decay=5e-4, on_step=net.hip_weights_changed)
+    df = net.default_bboxes.to(DEV)
+    ims = torch.from_numpy(synth.images(90, 32)).to(DEV)
+    tgs = torch.from_numpy(synth.targets(91, 32, g_max=8)).to(DEV)
+    losses = []
+    for _ in range(25):
+        opt.zero_grad()
+        loss = net.loss(net(ims), tgs, df)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses))
+    assert losses[-1] < 0.5 * losses[0], losses
+    assert np.mean(losses[-5:]) < np.mean(losses[:5])
+    assert all(torch.isfinite(v.float()).all() for v in net.state_dict().values())
