@@ -109,3 +109,19 @@ def test_train_entry_point_on_voc_tree(tmp_path, monkeypatch, capsys):
     assert (tmp_path / 'result' / 'detection' / 'weights.pth').exists()
     sd = torch.load(tmp_path / 'result' / 'detection' / 'weights.pth', map_location='cpu', weights_only=True)
     assert len(sd) == 173 and all(torch.isfinite(v.float()).all() for v in sd.values())
+
+
+def test_evaluate_and_inference_entry_points(tmp_path, monkeypatch, capsys):
+    """evaluate.py on the tiny VOC tree (evaluate.py:90-132 pipeline: ToTensor only) and inference.py on synthetic batches."""
+    from object_detection_torch2_amd import evaluate, inference
+    root = voc_fixture.make_tree(tmp_path / 'voc', list_name='test.txt')
+    monkeypatch.setattr(sys, 'argv', ['evaluate', '--data_dirs', str(root), '--batch_size', '2', '--num_workers', '0',
+                                      '--result_dir', str(tmp_path / 'result')])
+    evaluate.main()
+    out = capsys.readouterr().out
+    assert 'Finished Evaluate' in out
+    reports = list((tmp_path / 'result' / 'detection').glob('report_*.md'))
+    assert len(reports) == 1 and '|**mean**|' in reports[0].read_text()
+    monkeypatch.setattr(sys, 'argv', ['inference', '--batch_size', '2', '--result_dir', str(tmp_path / 'result')])
+    inference.main()
+    assert 'Finished' in capsys.readouterr().out
