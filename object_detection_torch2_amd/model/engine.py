@@ -93,6 +93,8 @@ class Engine:
         self.dist_hook = None  # callable(flat_grad) for data-parallel all-reduce (parallel.py)
         self._side = {}        # device -> side stream (heads / weight gradients)
         self.single_stream = os.environ.get('SSD_SINGLE_STREAM', '0') == '1'
+        self._fwd_done = None  # event: the last forward has consumed the backbone's outputs (backbone stream waits for it)
+        self._readers = {}     # backbone stage -> event of the last backward's weight gradient that read its output
         self.bf16 = False      # set per forward from module.compute_dtype; backward follows the saved forward
         self.prof = None       # list: when set, forward conv launches are bracketed by events (bench.py roofline leg)
 
@@ -154,24 +156,14 @@ class Engine:
         geo = self._geometry(H, W)
         f = dict(device=dev, dtype=torch.float32)
         b = dict(geo=geo, x4=torch.empty(N, H, W, 4, **f), z=[], pooled=[])
-        max_partial, cmax = 0, 0
         offs, p = [], 0
         for s, g in zip(self.stages, geo):
             b['z'].append(torch.empty(N, g['ho'], g['wo'], s.conv.cout, **f))
             b['pooled'].append(torch.empty(N, g['ha'], g['wa'], s.conv.cout, **f) if s.pool_pad is not None else None)
-            M = N * g['ho'] * g['wo']
-            # BN partial rows: one per 64-row m-tile (direct kernels, BM >= 64) or per 8 Winograd tiles (= 32 pixels)
-            max_partial = max(max_partial, ((M + 31) // 32 + 8) * s.conv.cout * 2)
-            cmax = max(cmax, s.conv.cout)
             if s.head is not None:           # heads read the activation BEFORE the pool (ssd.py:100-104 order)
                 offs.append(p)
                 p += g['ho'] * g['wo'] * s.head.anchors
         b['head_off'], b['P'] = offs, p
-        wino_v = wino_m = 0
-        for s, g in zip(self.stages, geo):
-            if s.conv.wino and self._wino_ok(g):
-                tp = (N * ((g['hi'] + 1) // 2) * ((g['wi'] + 1) // 2) + 127) // 128 * 128
-                wino_v, wino_m = max(wino_v, 16 * tp * s.conv.cin), max(wino_m, 16 * tp * s.conv.cout)
         b['head_v'] = {}
         head_m = 0
         for i, (s, g) in enumerate(zip(self.stages, geo)):
@@ -179,11 +171,28 @@ class Engine:
                 tp = (N * ((g['ho'] + 1) // 2) * ((g['wo'] + 1) // 2) + 127) // 128 * 128
                 b['head_v'][i] = torch.empty(16 * tp * s.head.cin, **f)
                 head_m = max(head_m, 16 * tp * s.head.co_pad)     # own workspace: the heads run on the side stream
-        b['wino_v'] = torch.empty(wino_v, **f) if wino_v else None
-        b['wino_m'] = torch.empty(wino_m, **f) if wino_m else None
         b['head_m'] = torch.empty(head_m, **f) if head_m else None
-        b['partial'] = torch.empty(max_partial, **f)
-        b['ws64'] = torch.empty(64 * cmax * 2, device=dev, dtype=torch.float64)
+
+        def workspace(stage_ids):
+            """BN partial table, fp64 scratch and Winograd V / M planes for one set of stages (one set per stream that runs them)."""
+            max_partial, cmax, wino_v, wino_m = 0, 1, 0, 0
+            for i in stage_ids:
+                s, g = self.stages[i], geo[i]
+                M = N * g['ho'] * g['wo']
+                # BN partial rows: one per 64-row m-tile (direct kernels, BM >= 64) or per 8 Winograd tiles; the 2x2 tiles of an
+                # odd map cover more than its pixels (19x19 -> 10x10 tiles), so count tiles, not pixels / 4
+                tiles = N * ((g['ho'] + 1) // 2) * ((g['wo'] + 1) // 2)
+                max_partial = max(max_partial, (max((M + 63) // 64, (tiles + 7) // 8) + 8) * s.conv.cout * 2)
+                cmax = max(cmax, s.conv.cout)
+                if s.conv.wino and self._wino_ok(g):
+                    tp = (N * ((g['hi'] + 1) // 2) * ((g['wi'] + 1) // 2) + 127) // 128 * 128
+                    wino_v, wino_m = max(wino_v, 16 * tp * s.conv.cin), max(wino_m, 16 * tp * s.conv.cout)
+            return dict(partial=torch.empty(max(max_partial, 1), **f), ws64=torch.empty(64 * cmax * 2, device=dev, dtype=torch.float64),
+                        wino_v=torch.empty(wino_v, **f) if wino_v else None, wino_m=torch.empty(wino_m, **f) if wino_m else None)
+
+        n_st = len(self.stages)
+        tail_ws = workspace(range(self.tail_start, n_st))
+        b['ws'] = [workspace(range(self.tail_start)) if self.tail_start > 0 else tail_ws, tail_ws]    # [backbone, tail]
         if len(self._bufs) >= 3:                 # keep the three most recent batch geometries (≈3.4 GB each at N=32)
             self._bufs.pop(next(iter(self._bufs)))
         self._bufs[key] = b
@@ -206,13 +215,13 @@ class Engine:
             spec.wino_key = key
         return spec.wino_u
 
-    def _conv_winograd(self, spec, x, xs, z, b, N, h, w, stats):
+    def _conv_winograd(self, spec, x, xs, z, ws, N, h, w, stats):
         """3x3/s1/p1 conv as input transform -> 16 plane GEMMs (one launch of the implicit-GEMM kernel) -> output transform.
         Returns the number of BN partial rows written to `stats`."""
         L, st = self.lib, _lib.stream()
         U = self._wino_weights(spec)
         _, bias = self._weight(spec)
-        V, Mo = b['wino_v'], b['wino_m']
+        V, Mo = ws['wino_v'], ws['wino_m']
         tp = (N * ((h + 1) // 2) * ((w + 1) // 2) + 127) // 128 * 128
         _lib.check(L.ssdhip_winograd_input(_lib.ptr(x), _lib.ptr(xs[0]) if xs is not None else None,
                                            _lib.ptr(xs[1]) if xs is not None else None, _lib.ptr(V), N, h, w, spec.cin, st), f'winograd_input {spec.name}')
@@ -309,10 +318,11 @@ class Engine:
             self.main = torch.cuda.current_stream(dev)
             self.side_stream = None if engine.single_stream else engine._side_stream(dev, which)
 
-        def side(self):
+        def side(self, after=None):
+            """after: the stream whose queue the side work must follow (default: the main stream)."""
             if self.side_stream is None:
                 return contextlib.nullcontext()
-            self.side_stream.wait_event(self.main.record_event())
+            self.side_stream.wait_event((after or self.main).record_event())
             return torch.cuda.stream(self.side_stream)
 
         def join(self):
@@ -328,11 +338,14 @@ class Engine:
                 self.main.wait_event(event)
 
     # ------------------------------------------------------------------------------------------------ forward
-    def forward(self, x, save):
+    def forward(self, x, save, ready_event=None):
         _lib.require_gpu(x)
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError(f'expected (N, 3, H, W) input, got {tuple(x.shape)}')
+        x_in = x
         x = _lib.f32c(x)
+        if x is not x_in:
+            ready_event = None      # a contiguous fp32 copy was just made on the caller's stream: its completion is what counts
         N, _, H, W = x.shape
         dev = x.device
         b = self._buffers(N, H, W, dev)
@@ -340,12 +353,25 @@ class Engine:
         training = self.m.training
         self.bf16 = self.m.compute_dtype == 'bf16'
         out = torch.empty(N, b['P'], self.row, device=dev, dtype=torch.float32)
-        st = _lib.stream()
-        _lib.check(self.lib.ssdhip_normalize_nchw_to_nhwc4(_lib.ptr(x), _lib.ptr(b['x4']), N, H, W, st), 'normalize')
-        cur, cur_xs = b['x4'], None
         acts = []            # per stage: (z, xform) read by its head, (tensor, xform) read by the next conv
         nbt = []
         fork = self._Fork(self, dev)
+        main = fork.main
+        # The frozen backbone depends on the images only, so it gets its own stream: the backbone of step i+1 starts as soon as
+        # its images are there and the previous forward has consumed the backbone's outputs, i.e. next to the tail backward and
+        # the optimizer of step i (small, latency-bound launches that cannot fill the chip).  The two buffers the backward still
+        # reads (input of det_4_3, input of conv_6_1) are guarded by the events their weight gradients leave in _readers.
+        bb = None if (self.single_stream or self.tail_start == 0) else self._side_stream(dev, which=2)
+        entry = main.record_event()
+        if fork.side_stream is not None:
+            fork.side_stream.wait_event(entry)               # `out` may reuse memory that step i's loss kernels still read
+        if bb is not None:
+            # ready_event (optional, from the caller): "x is complete".  With it the backbone does not queue behind the caller's
+            # stream, i.e. not behind the previous step's backward and optimizer; without it, it waits for everything enqueued.
+            bb.wait_event(ready_event if ready_event is not None else entry)
+            if self._fwd_done is not None:
+                bb.wait_event(self._fwd_done)                # the previous forward no longer reads z / pooled / BN state
+            x.record_stream(bb)                              # the allocator must not recycle x while the backbone stream reads it
         if save and self.tail_start > 0:
             # the optimizer just changed every trainable weight: repack them (forward + data-gradient layouts, Winograd U) on the
             # side stream while the frozen backbone runs; the later _pack / _wino_weights calls find their keys current
@@ -363,55 +389,67 @@ class Engine:
             prepacked = fork.mark()
         else:
             prepacked = None
+        with (torch.cuda.stream(bb) if bb is not None else contextlib.nullcontext()):
+            _lib.check(self.lib.ssdhip_normalize_nchw_to_nhwc4(_lib.ptr(x), _lib.ptr(b['x4']), N, H, W, _lib.stream()), 'normalize')
+        cur, cur_xs = b['x4'], None
         for i, (s, g) in enumerate(zip(self.stages, geo)):
             c = s.conv
             bnm = self.m.features[s.bn_name]
+            on_bb = bb is not None and i < self.tail_start
             if i == self.tail_start:
+                if bb is not None:
+                    main.wait_event(bb.record_event())       # backbone done: the tail continues on the caller's stream
                 fork.wait(prepacked)
+            ws = b['ws'][0 if i < self.tail_start else 1]
             z = b['z'][i]
             M = N * g['ho'] * g['wo']
             bst = self._bn_state(s.bn_name, c.cout, dev)
-            if c.wino and self._wino_ok(g) and not self.bf16:     # bf16 MFMA outruns the fp32 Winograd pipeline: direct kernel
-                rows = self._conv_winograd(c, cur, cur_xs, z, b, N, g['hi'], g['wi'], b['partial'] if training else None)
-            else:
-                bm = self._conv(c, cur, cur_xs, z.data_ptr(), g['ho'] * g['wo'] * c.cout, N, g['hi'], g['wi'], g['ho'], g['wo'],
-                                b['partial'] if training else None)
-                rows = (M + bm - 1) // bm
-            if training:
-                track = bnm.track_running_stats and bnm.running_mean is not None
-                mom = 0.1 if bnm.momentum is None else bnm.momentum
-                _lib.check(self.lib.ssdhip_bn_finalize(_lib.ptr(b['partial']), rows, c.cout, M, _lib.ptr(bnm.weight),
-                                                       _lib.ptr(bnm.bias), _lib.ptr(bnm.running_mean) if track else None,
-                                                       _lib.ptr(bnm.running_var) if track else None, mom, bnm.eps,
-                                                       _lib.ptr(bst['scale']), _lib.ptr(bst['shift']), _lib.ptr(bst['mean']),
-                                                       _lib.ptr(bst['invstd']), _lib.ptr(b['ws64']), st), f'batch_norm {s.bn_name}')
-                if track and bnm.num_batches_tracked is not None:
-                    nbt.append(bnm.num_batches_tracked)
-            else:
-                _lib.check(self.lib.ssdhip_bn_fold_eval(_lib.ptr(bnm.weight), _lib.ptr(bnm.bias), _lib.ptr(bnm.running_mean),
-                                                        _lib.ptr(bnm.running_var), bnm.eps, c.cout, _lib.ptr(bst['scale']),
-                                                        _lib.ptr(bst['shift']), st), f'batch_norm(eval) {s.bn_name}')
-            act_xs = (bst['scale'], bst['shift'])       # act_L = relu(z * scale + shift), never materialised
-            if s.pool_pad is not None:
-                pooled = b['pooled'][i]
-                _lib.check(self.lib.ssdhip_bn_relu_pool(_lib.ptr(z), _lib.ptr(bst['scale']), _lib.ptr(bst['shift']), _lib.ptr(pooled),
-                                                        N, g['ho'], g['wo'], c.cout, 1, s.pool_pad, st), f'pool after {c.name}')
-                cur, cur_xs = pooled, None
-            else:
-                cur, cur_xs = z, act_xs
-            acts.append((z, act_xs, cur, cur_xs))
-            if s.head is not None:
-                off = b['head_off'][s.head_index]
-                with fork.side():            # needs z and this stage's BN scale/shift only; writes its own rows of `out`
-                    if i in b['head_v'] and not self.bf16:
-                        self._head_winograd(s.head, z, act_xs, b['head_v'][i], b, ctypes.c_void_p(out.data_ptr() + off * self.row * 4),
-                                            b['P'] * self.row, N, g['ho'], g['wo'])
-                    else:
-                        self._conv(s.head, z, act_xs, out.data_ptr() + off * self.row * 4, b['P'] * self.row, N, g['ho'], g['wo'],
-                                   g['ho'], g['wo'], None)
+            with (torch.cuda.stream(bb) if on_bb else contextlib.nullcontext()):
+                if on_bb and i in self._readers:
+                    bb.wait_event(self._readers.pop(i))      # last backward's weight gradient that read this stage's output
+                st = _lib.stream()
+                if c.wino and self._wino_ok(g) and not self.bf16:     # bf16 MFMA outruns the fp32 Winograd pipeline: direct kernel
+                    rows = self._conv_winograd(c, cur, cur_xs, z, ws, N, g['hi'], g['wi'], ws['partial'] if training else None)
+                else:
+                    bm = self._conv(c, cur, cur_xs, z.data_ptr(), g['ho'] * g['wo'] * c.cout, N, g['hi'], g['wi'], g['ho'], g['wo'],
+                                    ws['partial'] if training else None)
+                    rows = (M + bm - 1) // bm
+                if training:
+                    track = bnm.track_running_stats and bnm.running_mean is not None
+                    mom = 0.1 if bnm.momentum is None else bnm.momentum
+                    _lib.check(self.lib.ssdhip_bn_finalize(_lib.ptr(ws['partial']), rows, c.cout, M, _lib.ptr(bnm.weight),
+                                                           _lib.ptr(bnm.bias), _lib.ptr(bnm.running_mean) if track else None,
+                                                           _lib.ptr(bnm.running_var) if track else None, mom, bnm.eps,
+                                                           _lib.ptr(bst['scale']), _lib.ptr(bst['shift']), _lib.ptr(bst['mean']),
+                                                           _lib.ptr(bst['invstd']), _lib.ptr(ws['ws64']), st), f'batch_norm {s.bn_name}')
+                    if track and bnm.num_batches_tracked is not None:
+                        nbt.append(bnm.num_batches_tracked)
+                else:
+                    _lib.check(self.lib.ssdhip_bn_fold_eval(_lib.ptr(bnm.weight), _lib.ptr(bnm.bias), _lib.ptr(bnm.running_mean),
+                                                            _lib.ptr(bnm.running_var), bnm.eps, c.cout, _lib.ptr(bst['scale']),
+                                                            _lib.ptr(bst['shift']), st), f'batch_norm(eval) {s.bn_name}')
+                act_xs = (bst['scale'], bst['shift'])       # act_L = relu(z * scale + shift), never materialised
+                if s.pool_pad is not None:
+                    pooled = b['pooled'][i]
+                    _lib.check(self.lib.ssdhip_bn_relu_pool(_lib.ptr(z), _lib.ptr(bst['scale']), _lib.ptr(bst['shift']), _lib.ptr(pooled),
+                                                            N, g['ho'], g['wo'], c.cout, 1, s.pool_pad, st), f'pool after {c.name}')
+                    cur, cur_xs = pooled, None
+                else:
+                    cur, cur_xs = z, act_xs
+                acts.append((z, act_xs, cur, cur_xs))
+                if s.head is not None:
+                    off = b['head_off'][s.head_index]
+                    with fork.side(after=bb if on_bb else None):   # needs z and this stage's BN scale/shift only; writes its own rows of `out`
+                        if i in b['head_v'] and not self.bf16:
+                            self._head_winograd(s.head, z, act_xs, b['head_v'][i], b, ctypes.c_void_p(out.data_ptr() + off * self.row * 4),
+                                                b['P'] * self.row, N, g['ho'], g['wo'])
+                        else:
+                            self._conv(s.head, z, act_xs, out.data_ptr() + off * self.row * 4, b['P'] * self.row, N, g['ho'], g['wo'],
+                                       g['ho'], g['wo'], None)
         fork.join()
         if nbt:
             torch._foreach_add_(nbt, 1)
+        self._fwd_done = main.record_event() if bb is not None else None
         self._saved = dict(b=b, N=N, acts=acts, training=training, bf16=self.bf16) if save else None
         return out
 
@@ -539,6 +577,7 @@ class Engine:
                 x, xs = acts[i][0], acts[i][1]
                 with fork.side():
                     self._wgrad(s.head, x, xs, bw['dyh'][i], views, bw, N, g['ho'], g['wo'], g['ho'], g['wo'], None if self.bf16 else b['head_v'].get(i))
+                self._readers[i] = fork.mark()          # the next backbone pass may overwrite z[i] / its BN state after this
         last = len(self.stages) - 1
         for i in range(last, self.tail_start - 1, -1):
             s, g = self.stages[i], geo[i]
@@ -560,7 +599,7 @@ class Engine:
             _lib.check(L.ssdhip_bn_relu_bwd_finalize(_lib.ptr(bw['partial']), mb, c.cout, M,
                                                      _lib.ptr(views[f'features.{s.bn_name}.weight']),
                                                      _lib.ptr(views[f'features.{s.bn_name}.bias']), _lib.ptr(bw['coef']),
-                                                     _lib.ptr(b['ws64']), st), 'bn_relu_bwd_finalize')
+                                                     _lib.ptr(b['ws'][1]['ws64']), st), 'bn_relu_bwd_finalize')
             _lib.check(L.ssdhip_bn_relu_bwd_apply(_lib.ptr(z), _lib.ptr(da), _lib.ptr(bst['scale']), _lib.ptr(bst['shift']),
                                                   _lib.ptr(bst['mean']), _lib.ptr(bst['invstd']), _lib.ptr(bw['coef']), M, c.cout,
                                                   _lib.ptr(dz), st), 'bn_relu_bwd_apply')
@@ -574,6 +613,8 @@ class Engine:
                 self.dist_hook.start(flat, cut, flat.numel())
             with fork.side():
                 self._wgrad(c, xin, xin_xs, dz, views, bw, N, g['hi'], g['wi'], g['ho'], g['wo'])
+            if i == self.tail_start and i > 0:
+                self._readers[i - 1] = fork.mark()      # conv_6_1's weight gradient reads the backbone's last activation
             if i > self.tail_start:
                 prev, gp = self.stages[i - 1], geo[i - 1]
                 if prev.pool_pad is None:

@@ -29,7 +29,8 @@ class _SSDForward(torch.autograd.Function):
         ctx.net = net
         ctx.token = object()
         net._engine_token = ctx.token
-        return net._engine().forward(x, save=True)
+        ev, net._ready_event = net._ready_event, None
+        return net._engine().forward(x, save=True, ready_event=ev)
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -94,6 +95,7 @@ class SSD(nn.Module):
         self._hip_epoch = 0
         self._eng = None
         self._tune_all = False
+        self._ready_event = None
         self.compute_dtype = 'fp32'      # 'bf16': see set_compute_dtype
         self._engine_token = None
         self._default_bboxes = None      # generated lazily by the HIP kernel (first access needs the GPU)
@@ -195,13 +197,17 @@ class SSD(nn.Module):
         """Tell the engine that trainable weights were updated outside torch's version counter (FusedAdam)."""
         self._hip_epoch += 1
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """(N, 3, 300, 300) float[0,1] -> (N, P, 4 + C) on x.device (ssd.py:86-106, documented contract)."""
+    def forward(self, x: torch.Tensor, ready_event: torch.cuda.Event = None) -> torch.Tensor:
+        """(N, 3, 300, 300) float[0,1] -> (N, P, 4 + C) on x.device (ssd.py:86-106, documented contract).
+        ready_event (extension, optional): an event after which `x` is complete.  The frozen backbone runs on its own stream; given
+        this event it starts as soon as x is ready instead of queueing behind everything on the caller's stream -- the
+        backbone of step i+1 then overlaps the tail backward and optimizer of step i (same results, see engine.py)."""
         _lib.require_gpu(x)
         params = [p for _, p in self.named_train_params()]
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            self._ready_event = ready_event
             return _SSDForward.apply(self, x, *params)
-        return self._engine().forward(x, save=False)
+        return self._engine().forward(x, save=False, ready_event=ready_event)
 
     def finetune_backbone(self, enable: bool = True):
         """Extension: un-freeze the VGG16-bn backbone.  The reference never does (ssd.py:31-32; 72.2 -> 187.9
