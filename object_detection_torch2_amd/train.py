@@ -96,11 +96,22 @@ def main():
         running = torch.zeros((), device=device)
         t0 = time.perf_counter()
         n_steps = 0
-        for ims, gts in batches(epoch):
+        # one batch of lookahead: batch i+1 is uploaded (and augmented) between the loss and the backward of step i, and its
+        # "ready" event lets the frozen backbone of step i+1 run next to step i's tail backward and optimizer (engine.py)
+        source = batches(epoch)
+
+        def fetch():
+            item = next(source, None)
+            return None if item is None else (item[0], item[1], torch.cuda.current_stream().record_event())
+
+        cur = fetch()
+        while cur is not None:
+            ims, gts, ready = cur
             n_steps += 1
             optimizer.zero_grad()
-            outputs = net(ims)
+            outputs = net(ims, ready_event=ready)
             loss = net.loss(outputs=outputs, targets=gts, default_bboxes=defaults)
+            cur = fetch()
             loss.backward()
             optimizer.step()
             running += loss.detach()
