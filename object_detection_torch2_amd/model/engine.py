@@ -93,8 +93,8 @@ class Engine:
         self.dist_hook = None  # callable(flat_grad) for data-parallel all-reduce (parallel.py)
         self._side = {}        # device -> side stream (heads / weight gradients)
         self.single_stream = os.environ.get('SSD_SINGLE_STREAM', '0') == '1'
-        self._fwd_done = None  # event: the last forward has consumed the backbone's outputs (backbone stream waits for it)
-        self._readers = {}     # backbone stage -> event of the last backward's weight gradient that read its output
+        self._readers = {}     # backbone stage -> events after which its output / BN state may be overwritten by the next
+                               # backbone pass: the forward consumers (det_4_3 head, conv_6_1) and their weight gradients
         self.bf16 = False      # set per forward from module.compute_dtype; backward follows the saved forward
         self.prof = None       # list: when set, forward conv launches are bracketed by events (bench.py roofline leg)
 
@@ -303,6 +303,10 @@ class Engine:
         return bm
 
     # ------------------------------------------------------------------------------------------------ streams
+    def _note_reader(self, stage, event):
+        if event is not None and not self.single_stream and self.tail_start > 0:
+            self._readers.setdefault(stage, []).append(event)
+
     def _side_stream(self, dev, which=0):
         st = self._side.get((dev, which))
         if st is None:
@@ -358,9 +362,9 @@ class Engine:
         fork = self._Fork(self, dev)
         main = fork.main
         # The frozen backbone depends on the images only, so it gets its own stream: the backbone of step i+1 starts as soon as
-        # its images are there and the previous forward has consumed the backbone's outputs, i.e. next to the tail backward and
-        # the optimizer of step i (small, latency-bound launches that cannot fill the chip).  The two buffers the backward still
-        # reads (input of det_4_3, input of conv_6_1) are guarded by the events their weight gradients leave in _readers.
+        # its images are there, i.e. next to the tail forward, the tail backward and the optimizer of step i (small, latency-bound
+        # launches that cannot fill the chip).  Only two backbone outputs have consumers outside the backbone stream -- the inputs
+        # of det_4_3 and of conv_6_1 (forward and weight gradient): those stages wait for the events their readers leave in _readers.
         bb = None if (self.single_stream or self.tail_start == 0) else self._side_stream(dev, which=2)
         entry = main.record_event()
         if fork.side_stream is not None:
@@ -369,8 +373,6 @@ class Engine:
             # ready_event (optional, from the caller): "x is complete".  With it the backbone does not queue behind the caller's
             # stream, i.e. not behind the previous step's backward and optimizer; without it, it waits for everything enqueued.
             bb.wait_event(ready_event if ready_event is not None else entry)
-            if self._fwd_done is not None:
-                bb.wait_event(self._fwd_done)                # the previous forward no longer reads z / pooled / BN state
             x.record_stream(bb)                              # the allocator must not recycle x while the backbone stream reads it
         if save and self.tail_start > 0:
             # the optimizer just changed every trainable weight: repack them (forward + data-gradient layouts, Winograd U) on the
@@ -405,8 +407,9 @@ class Engine:
             M = N * g['ho'] * g['wo']
             bst = self._bn_state(s.bn_name, c.cout, dev)
             with (torch.cuda.stream(bb) if on_bb else contextlib.nullcontext()):
-                if on_bb and i in self._readers:
-                    bb.wait_event(self._readers.pop(i))      # last backward's weight gradient that read this stage's output
+                if on_bb:
+                    for ev in self._readers.pop(i, ()):      # last step's readers of this stage's output / BN state
+                        bb.wait_event(ev)
                 st = _lib.stream()
                 if c.wino and self._wino_ok(g) and not self.bf16:     # bf16 MFMA outruns the fp32 Winograd pipeline: direct kernel
                     rows = self._conv_winograd(c, cur, cur_xs, z, ws, N, g['hi'], g['wi'], ws['partial'] if training else None)
@@ -414,6 +417,8 @@ class Engine:
                     bm = self._conv(c, cur, cur_xs, z.data_ptr(), g['ho'] * g['wo'] * c.cout, N, g['hi'], g['wi'], g['ho'], g['wo'],
                                     ws['partial'] if training else None)
                     rows = (M + bm - 1) // bm
+                if bb is not None and i == self.tail_start:
+                    self._note_reader(i - 1, main.record_event())     # the backbone's last activation is consumed
                 if training:
                     track = bnm.track_running_stats and bnm.running_mean is not None
                     mom = 0.1 if bnm.momentum is None else bnm.momentum
@@ -446,10 +451,11 @@ class Engine:
                         else:
                             self._conv(s.head, z, act_xs, out.data_ptr() + off * self.row * 4, b['P'] * self.row, N, g['ho'], g['wo'],
                                        g['ho'], g['wo'], None)
+                    if on_bb:
+                        self._note_reader(i, fork.mark())
         fork.join()
         if nbt:
             torch._foreach_add_(nbt, 1)
-        self._fwd_done = main.record_event() if bb is not None else None
         self._saved = dict(b=b, N=N, acts=acts, training=training, bf16=self.bf16) if save else None
         return out
 
@@ -577,7 +583,7 @@ class Engine:
                 x, xs = acts[i][0], acts[i][1]
                 with fork.side():
                     self._wgrad(s.head, x, xs, bw['dyh'][i], views, bw, N, g['ho'], g['wo'], g['ho'], g['wo'], None if self.bf16 else b['head_v'].get(i))
-                self._readers[i] = fork.mark()          # the next backbone pass may overwrite z[i] / its BN state after this
+                self._note_reader(i, fork.mark())    # the next backbone pass may overwrite z[i] / its BN state after this
         last = len(self.stages) - 1
         for i in range(last, self.tail_start - 1, -1):
             s, g = self.stages[i], geo[i]
@@ -614,7 +620,7 @@ class Engine:
             with fork.side():
                 self._wgrad(c, xin, xin_xs, dz, views, bw, N, g['hi'], g['wi'], g['ho'], g['wo'])
             if i == self.tail_start and i > 0:
-                self._readers[i - 1] = fork.mark()      # conv_6_1's weight gradient reads the backbone's last activation
+                self._note_reader(i - 1, fork.mark())   # conv_6_1's weight gradient reads the backbone's last activation
             if i > self.tail_start:
                 prev, gp = self.stages[i - 1], geo[i - 1]
                 if prev.pool_pad is None:

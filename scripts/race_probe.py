@@ -15,10 +15,12 @@ def run(single, sync_each, overlap=False):
     net._engine().single_stream = single
     opt = FusedAdam(net.train_params(), lr=1e-3, weight_decay=5e-4, on_step=net.hip_weights_changed)
     df = net.default_bboxes.to(DEV)
-    ims = torch.from_numpy(synth.images(90, N)).to(DEV); tgs = torch.from_numpy(synth.targets(91, N, g_max=8)).to(DEV)
+    # different images every step: a backbone pass that overwrote a buffer too early would change the result
+    data = [(torch.from_numpy(synth.images(90 + k, N)).to(DEV), torch.from_numpy(synth.targets(190 + k, N, g_max=8)).to(DEV)) for k in range(5)]
     torch.cuda.synchronize(); ev = torch.cuda.current_stream().record_event() if overlap else None
     losses = []
-    for _ in range(STEPS):
+    for it in range(STEPS):
+        ims, tgs = data[it % 5]
         opt.zero_grad(); loss = net.loss(net(ims, ready_event=ev), tgs, df); loss.backward(); opt.step()
         losses.append(loss.item() if sync_each else loss)
     ls = [l if isinstance(l, float) else l.item() for l in losses]
