@@ -193,6 +193,13 @@ int ssdhip_adam_multi_tensor(const void* const* table, const int64_t* sizes, con
  * adam_tick increments the device step counter and refreshes slots 5,6 (graph-replayable step bookkeeping).  */
 int ssdhip_adam_tick(int32_t* step, float* hyper, void* stream);
 
+/* ---- A3  conv_1_1 (model/vgg16.py:25,33: nn.Conv2d(3, 64, 3, padding=1) on the normalised image) as a dedicated HBM-bound
+ * kernel: x (N,H,W,4) fp32 (RGB padded to 4), w OIHW (64,3,3,3) unpacked, z (N,H,W,64), stats NULL or
+ * (ssdhip_conv_rgb3x3_stat_rows, 64, 2) per-wave partial [sum, sumsq] for train-mode BatchNorm.                          */
+int ssdhip_conv_rgb3x3_stat_rows(int N, int H, int W);
+int ssdhip_conv_rgb3x3(const float* x_nhwc4, const float* w_oihw, const float* bias, float* z, float* stats, int N, int H, int W, int Cout,
+                       void* stream);
+
 /* ---- 8(f)-4  full fine-tuning (train.py:69-74 un-freezes nothing; extension): backward of MaxPool2d(2,2,pad) over the
  * recomputed a = relu(z*scale+shift) (vgg16.py:28-35): dpooled (N,Ho,Wo,C) -> da (N,H,W,C), gradient to the first maximum
  * of each window in scan order (ATen rule).                                                                            */

@@ -74,6 +74,8 @@ SIGNATURES = {
     'ssdhip_scatter_head_grad': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ssdhip_adam_multi_tensor': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'ssdhip_adam_tick': (c_int, [c_void_p, c_void_p, c_void_p]),
+    'ssdhip_conv_rgb3x3_stat_rows': (c_int, [c_int, c_int, c_int]),
+    'ssdhip_conv_rgb3x3': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'ssdhip_bn_relu_pool_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ssdhip_augment_row_floats': (c_int, []),
     'ssdhip_augment_ws_bytes': (c_int64, [c_int]),

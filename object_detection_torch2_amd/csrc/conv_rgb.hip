@@ -1,0 +1,119 @@
+// conv_1_1 (model/vgg16.py:25,33: Conv2d(3, 64, 3, padding=1) on the normalised image) as its own kernel.
+// The layer is a store: 46 MB in, 737 MB out at batch 32, 0.3 GFLOP per image -- HBM-bound, and the general implicit-GEMM
+// kernel spends it on pipeline fill/drain (one K-step per tile: 0.42 ms = 1.75 TB/s).  Here:
+//   * no LDS, no barriers: a wave owns 32 consecutive pixels x all Cout channels per iteration and walks the image persistently;
+//   * the A operand of v_mfma_f32_32x32x2_f32 comes straight from global memory: lane (pixel = lane & 31, half = lane >> 5) loads
+//     the float4 (r, g, b, 0) of tap 2 q + half for q = 0..4 (tap 9 = zero), and MFMA (q, c) takes channel c of it -- lanes
+//     0-31 feed k = (tap 2 q, c), lanes 32-63 k = (tap 2 q + 1, c); the B operand holds the weights in the same k order,
+//     resident in 30 registers for the whole kernel (read once from the OIHW tensor, no packing);
+//   * epilogue per iteration: + bias, NHWC store (each store instruction writes two full 128-B lines), per-lane running sums
+//     for the BatchNorm statistics, written once per wave at the end (one partial row per wave: fixed assignment, deterministic).
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NT>       // Cout = 32 NT
+__global__ __launch_bounds__(256) void conv_rgb3x3_kernel(const float4* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                          float* __restrict__ z, float* __restrict__ stats, int N, int H, int W) {
+    constexpr int COUT = 32 * NT;
+    const int lane = threadIdx.x & 63, half = lane >> 5, prow = lane & 31;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const int64_t M = (int64_t)N * H * W;
+    const int64_t tiles = (M + 31) / 32;
+
+    float bw[5][3][NT];                                   // weights in operand order, see above
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int t = 2 * q + half;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bw[q][c][j] = t < 9 ? w[((size_t)(prow + 32 * j) * 3 + c) * 9 + t] : 0.f;
+    }
+    float bv[NT], s1[NT], s2[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { bv[j] = bias ? bias[prow + 32 * j] : 0.f; s1[j] = 0.f; s2[j] = 0.f; }
+
+    for (int64_t tile = wave; tile < tiles; tile += nwaves) {
+        const int64_t p = tile * 32 + prow;               // this lane's pixel (A-operand row)
+        const bool pv = p < M;
+        const int64_t pc = pv ? p : M - 1;
+        const int n = (int)(pc / ((int64_t)H * W));
+        const int rem = (int)(pc - (int64_t)n * H * W);
+        const int y = rem / W, xx = rem - y * W;
+        float4 a[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int t = 2 * q + half;
+            const int r = t / 3, s = t - 3 * r;
+            const int yy = y + r - 1, xs = xx + s - 1;
+            const bool ok = pv && t < 9 && (unsigned)yy < (unsigned)H && (unsigned)xs < (unsigned)W;
+            a[q] = ok ? x[((size_t)n * H + yy) * W + xs] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        f32x16 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float av = c == 0 ? a[q].x : c == 1 ? a[q].y : a[q].z;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw[q][c][j], acc[j], 0, 0, 0);
+            }
+        // C/D map: column = lane & 31 (+ 32 j), row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int co = prow + 32 * j;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t m = tile * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (m < M) {
+                    const float v = acc[j][e] + bv[j];
+                    z[m * COUT + co] = v;
+                    s1[j] += v; s2[j] += v * v;
+                }
+            }
+        }
+    }
+    if (stats != nullptr) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64), t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+            if (half == 0) *reinterpret_cast<float2*>(stats + ((size_t)wave * COUT + prow + 32 * j) * 2) = make_float2(t1, t2);
+        }
+    }
+}
+
+int rgb_grid(int64_t M) {
+    const int64_t tiles = (M + 31) / 32;
+    int64_t blocks = (tiles + 3) / 4;
+    if (blocks > 256 * 4) blocks = 256 * 4;              // one round of resident blocks (124 registers: 4 blocks per CU)
+    return (int)blocks;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssdhip_conv_rgb3x3_stat_rows(int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return SSDHIP_EINVAL;
+    return rgb_grid((int64_t)N * H * W) * 4;
+}
+
+int ssdhip_conv_rgb3x3(const float* x_nhwc4, const float* w_oihw, const float* bias, float* z, float* stats, int N, int H, int W, int Cout,
+                       void* stream) {
+    SSDHIP_REQUIRE(x_nhwc4 && w_oihw && z && N > 0 && H > 0 && W > 0, "conv_rgb3x3: bad arguments");
+    SSDHIP_REQUIRE(Cout == 64, "conv_rgb3x3: built for Cout = 64 (VGG16 conv_1_1)");
+    SSDHIP_REQUIRE((int64_t)N * H * W < (1ll << 31), "conv_rgb3x3: tensor too large");
+    hipLaunchKernelGGL(conv_rgb3x3_kernel<2>, dim3(rgb_grid((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(x_nhwc4), w_oihw, bias, z, stats, N, H, W);
+    SSDHIP_CHECK_LAUNCH();
+    return SSDHIP_OK;
+}
+
+}  // extern "C"

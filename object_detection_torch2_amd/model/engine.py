@@ -182,7 +182,7 @@ class Engine:
                 # BN partial rows: one per 64-row m-tile (direct kernels, BM >= 64) or per 8 Winograd tiles; the 2x2 tiles of an
                 # odd map cover more than its pixels (19x19 -> 10x10 tiles), so count tiles, not pixels / 4
                 tiles = N * ((g['ho'] + 1) // 2) * ((g['wo'] + 1) // 2)
-                max_partial = max(max_partial, (max((M + 63) // 64, (tiles + 7) // 8) + 8) * s.conv.cout * 2)
+                max_partial = max(max_partial, (max((M + 63) // 64, (tiles + 7) // 8, 4096 if s.conv.cin_pad == 4 else 0) + 8) * s.conv.cout * 2)
                 cmax = max(cmax, s.conv.cout)
                 if s.conv.wino and self._wino_ok(g):
                     tp = (N * ((g['hi'] + 1) // 2) * ((g['wi'] + 1) // 2) + 127) // 128 * 128
@@ -413,6 +413,13 @@ class Engine:
                 st = _lib.stream()
                 if c.wino and self._wino_ok(g) and not self.bf16:     # bf16 MFMA outruns the fp32 Winograd pipeline: direct kernel
                     rows = self._conv_winograd(c, cur, cur_xs, z, ws, N, g['hi'], g['wi'], ws['partial'] if training else None)
+                elif c.cin_pad == 4 and c.cout == 64 and c.k == 3 and c.stride == 1 and c.pad == 1:
+                    # conv_1_1: a 737 MB store with 0.3 GFLOP per image -- its own HBM-bound kernel (conv_rgb.hip), unpacked weights
+                    w1, b1 = self._weight(c)
+                    rows = self.lib.ssdhip_conv_rgb3x3_stat_rows(N, g['hi'], g['wi'])
+                    _lib.check(self.lib.ssdhip_conv_rgb3x3(_lib.ptr(cur), _lib.ptr(w1), _lib.ptr(b1) if b1 is not None else None, _lib.ptr(z),
+                                                           _lib.ptr(ws['partial']) if training else None, N, g['hi'], g['wi'], c.cout, st),
+                               f'conv2d {c.name}')
                 else:
                     bm = self._conv(c, cur, cur_xs, z.data_ptr(), g['ho'] * g['wo'] * c.cout, N, g['hi'], g['wi'], g['ho'], g['wo'],
                                     ws['partial'] if training else None)

@@ -58,6 +58,21 @@ def conv2d_nhwc(x, w_oihw, bias=None, stride=1, pad=0, in_scale=None, in_shift=N
     return z, stats
 
 
+def conv_rgb3x3(x4, w_oihw, bias=None, want_stats=False):
+    """conv_1_1: x4 (N,H,W,4) fp32 (RGB padded to 4), w (64,3,3,3) -> (z (N,H,W,64), per-wave partial stats or None)."""
+    _lib.require_gpu(x4, w_oihw)
+    lib = _lib.load()
+    N, H, W, C = x4.shape
+    if C != 4 or tuple(w_oihw.shape[1:]) != (3, 3, 3):
+        raise ValueError(f'conv_rgb3x3: expected (N,H,W,4) input and (Cout,3,3,3) weights, got {tuple(x4.shape)} {tuple(w_oihw.shape)}')
+    cout = w_oihw.shape[0]
+    z = torch.empty(N, H, W, cout, device=x4.device, dtype=torch.float32)
+    stats = torch.empty(lib.ssdhip_conv_rgb3x3_stat_rows(N, H, W), cout, 2, device=x4.device, dtype=torch.float32) if want_stats else None
+    _lib.check(lib.ssdhip_conv_rgb3x3(_lib.ptr(x4), _lib.ptr(_lib.f32c(w_oihw)), _lib.ptr(bias) if bias is not None else None, _lib.ptr(z),
+                                      _lib.ptr(stats) if stats is not None else None, N, H, W, cout, _lib.stream()), 'conv_rgb3x3')
+    return z, stats
+
+
 def conv2d_dgrad(dy, w_oihw, in_hw, stride=1, pad=0, accumulate_into=None, tile=0, bf16=False):
     """dy (N,Ho,Wo,Cout_pad) -> dx (N,Hi,Wi,Cin): data gradient of conv2d(x, w, stride, pad)."""
     _lib.require_gpu(dy, w_oihw)

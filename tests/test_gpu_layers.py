@@ -60,6 +60,26 @@ def test_conv_forward(case):
     assert torch.equal(z, z2)
 
 
+@pytest.mark.parametrize('N,H,W', [(2, 9, 7), (3, 21, 17), (2, 64, 48), (4, 300, 300)])
+def test_conv_rgb3x3_dedicated_kernel(N, H, W):
+    """conv_1_1's own kernel (operands straight from global memory, weights resident in registers) vs F.conv2d."""
+    from object_detection_torch2_amd import ops
+    x = rnd(N, 3, H, W, seed=31)
+    w = rnd(64, 3, 3, 3, seed=32, scale=(2.0 / 27) ** 0.5)
+    b = rnd(64, seed=33)
+    ref = F.conv2d(x, w, b, padding=1)
+    xg = ops.to_nhwc(x.to(DEV), pad_to=4)
+    z, stats = ops.conv_rgb3x3(xg, w.to(DEV), b.to(DEV), want_stats=True)
+    assert rel_err(z.permute(0, 3, 1, 2).cpu(), ref) < 2e-6                    # K = 27
+    s = stats.sum(dim=0).cpu()
+    assert torch.allclose(s[:, 0], ref.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(s[:, 1], (ref * ref).sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3)
+    z2, st2 = ops.conv_rgb3x3(xg, w.to(DEV), b.to(DEV), want_stats=True)
+    assert torch.equal(z, z2) and torch.equal(stats, st2)                       # deterministic replay
+    z3, none = ops.conv_rgb3x3(xg, w.to(DEV))
+    assert none is None and rel_err(z3.permute(0, 3, 1, 2).cpu(), F.conv2d(x, w, None, padding=1)) < 2e-6
+
+
 def test_conv_fused_input_transform_and_padding():
     """a = relu(z*scale+shift) applied while staging; zero padding must be applied AFTER the transform."""
     from object_detection_torch2_amd import ops
