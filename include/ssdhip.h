@@ -200,6 +200,17 @@ int ssdhip_conv_rgb3x3_stat_rows(int N, int H, int W);
 int ssdhip_conv_rgb3x3(const float* x_nhwc4, const float* w_oihw, const float* bias, float* z, float* stats, int N, int H, int W, int Cout,
                        void* stream);
 
+/* ---- A3  the Cin = 64 3x3/s1/p1 layers on big maps (conv_1_2, conv_2_1; model/vgg16.py:25,33): K = 576 is too short for the
+ * staged implicit-GEMM kernel; here the A operand comes straight from global memory and the weights stay in LDS.
+ * x (N,H,W,64), wimg = ssdhip_conv_c64_pack(w OIHW (Cout,64,3,3)) of ssdhip_conv_c64_weight_floats(Cout) floats, optional fused
+ * BN.ReLU of the input (in_scale/in_shift, 64 each), z (N,H,W,Cout), stats NULL or (ssdhip_conv_c64_stat_rows(Cout), Cout, 2).
+ * Cout = 64, 128 or 256.                                                                                                */
+int64_t ssdhip_conv_c64_weight_floats(int Cout);
+int ssdhip_conv_c64_pack(const float* w_oihw, float* wimg, int Cout, void* stream);
+int ssdhip_conv_c64_stat_rows(int Cout);
+int ssdhip_conv_c64(const float* x, const float* wimg, const float* bias, const float* in_scale, const float* in_shift, float* z,
+                    float* stats, int N, int H, int W, int Cout, void* stream);
+
 /* ---- 8(f)-4  full fine-tuning (train.py:69-74 un-freezes nothing; extension): backward of MaxPool2d(2,2,pad) over the
  * recomputed a = relu(z*scale+shift) (vgg16.py:28-35): dpooled (N,Ho,Wo,C) -> da (N,H,W,C), gradient to the first maximum
  * of each window in scan order (ATen rule).                                                                            */

@@ -413,6 +413,24 @@ class Engine:
                 st = _lib.stream()
                 if c.wino and self._wino_ok(g) and not self.bf16:     # bf16 MFMA outruns the fp32 Winograd pipeline: direct kernel
                     rows = self._conv_winograd(c, cur, cur_xs, z, ws, N, g['hi'], g['wi'], ws['partial'] if training else None)
+                elif (c.cin == 64 and c.cout in (64, 128) and c.k == 3 and c.stride == 1 and c.pad == 1 and min(g['hi'], g['wi']) >= 100
+                      and not self.bf16):
+                    # conv_1_2 / conv_2_1: K = 576 is too short for the staged kernel (103-108 TF); conv_c64.hip feeds the MFMAs from
+                    # global memory with the weights resident in LDS (112-127 TF, scripts/c64_bench.py)
+                    w1, b1 = self._weight(c)
+                    key = (w1.data_ptr(), w1._version, self.m._hip_epoch if not c.frozen else 0)
+                    if getattr(c, 'c64_img', None) is None or c.c64_img.device != w1.device:
+                        c.c64_img = torch.empty(self.lib.ssdhip_conv_c64_weight_floats(c.cout), device=w1.device, dtype=torch.float32)
+                        c.c64_key = None
+                    if c.c64_key != key:
+                        _lib.check(self.lib.ssdhip_conv_c64_pack(_lib.ptr(w1), _lib.ptr(c.c64_img), c.cout, st), f'conv_c64_pack {c.name}')
+                        c.c64_key = key
+                    rows = self.lib.ssdhip_conv_c64_stat_rows(c.cout)
+                    _lib.check(self.lib.ssdhip_conv_c64(_lib.ptr(cur), _lib.ptr(c.c64_img), _lib.ptr(b1) if b1 is not None else None,
+                                                        _lib.ptr(cur_xs[0]) if cur_xs is not None else None,
+                                                        _lib.ptr(cur_xs[1]) if cur_xs is not None else None, _lib.ptr(z),
+                                                        _lib.ptr(ws['partial']) if training else None, N, g['hi'], g['wi'], c.cout, st),
+                               f'conv2d {c.name}')
                 elif c.cin_pad == 4 and c.cout == 64 and c.k == 3 and c.stride == 1 and c.pad == 1:
                     # conv_1_1: a 737 MB store with 0.3 GFLOP per image -- its own HBM-bound kernel (conv_rgb.hip), unpacked weights
                     w1, b1 = self._weight(c)

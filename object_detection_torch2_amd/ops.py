@@ -73,6 +73,24 @@ def conv_rgb3x3(x4, w_oihw, bias=None, want_stats=False):
     return z, stats
 
 
+def conv_c64(x, w_oihw, bias=None, in_scale=None, in_shift=None, want_stats=False):
+    """3x3/s1/p1 conv with Cin = 64 (conv_1_2 / conv_2_1 kernel): x (N,H,W,64) -> (z (N,H,W,Cout), per-wave partial stats or None)."""
+    _lib.require_gpu(x, w_oihw)
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    cout = w_oihw.shape[0]
+    if C != 64 or tuple(w_oihw.shape[1:]) != (64, 3, 3):
+        raise ValueError(f'conv_c64: expected (N,H,W,64) input and (Cout,64,3,3) weights, got {tuple(x.shape)} {tuple(w_oihw.shape)}')
+    wimg = torch.empty(_lib.check(lib.ssdhip_conv_c64_weight_floats(cout), 'conv_c64_weight_floats'), device=x.device, dtype=torch.float32)
+    _lib.check(lib.ssdhip_conv_c64_pack(_lib.ptr(_lib.f32c(w_oihw)), _lib.ptr(wimg), cout, _lib.stream()), 'conv_c64_pack')
+    z = torch.empty(N, H, W, cout, device=x.device, dtype=torch.float32)
+    stats = torch.empty(lib.ssdhip_conv_c64_stat_rows(cout), cout, 2, device=x.device, dtype=torch.float32) if want_stats else None
+    _lib.check(lib.ssdhip_conv_c64(_lib.ptr(x), _lib.ptr(wimg), _lib.ptr(bias) if bias is not None else None,
+                                   _lib.ptr(in_scale) if in_scale is not None else None, _lib.ptr(in_shift) if in_shift is not None else None,
+                                   _lib.ptr(z), _lib.ptr(stats) if stats is not None else None, N, H, W, cout, _lib.stream()), 'conv_c64')
+    return z, stats
+
+
 def conv2d_dgrad(dy, w_oihw, in_hw, stride=1, pad=0, accumulate_into=None, tile=0, bf16=False):
     """dy (N,Ho,Wo,Cout_pad) -> dx (N,Hi,Wi,Cin): data gradient of conv2d(x, w, stride, pad)."""
     _lib.require_gpu(dy, w_oihw)

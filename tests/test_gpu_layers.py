@@ -80,6 +80,29 @@ def test_conv_rgb3x3_dedicated_kernel(N, H, W):
     assert none is None and rel_err(z3.permute(0, 3, 1, 2).cpu(), F.conv2d(x, w, None, padding=1)) < 2e-6
 
 
+@pytest.mark.parametrize('N,H,W,cout,xform', [(2, 9, 7, 64, True), (3, 21, 17, 128, False), (2, 64, 48, 64, False), (2, 150, 150, 128, True),
+                                               (1, 33, 31, 256, True)])
+def test_conv_c64_kernel(N, H, W, cout, xform):
+    """The Cin = 64 kernel (A operand from global memory, weights resident in LDS) vs F.conv2d, with and without the fused
+    BN.ReLU of its input (zero padding after the transform)."""
+    from object_detection_torch2_amd import ops
+    zprev = rnd(N, 64, H, W, seed=41)
+    w = rnd(cout, 64, 3, 3, seed=42, scale=(2.0 / 576) ** 0.5)
+    b = rnd(cout, seed=43)
+    scale, shift = rnd(64, seed=44), rnd(64, seed=45) + 0.5
+    a = F.relu(zprev * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)) if xform else zprev
+    ref = F.conv2d(a, w, b, padding=1)
+    z, stats = ops.conv_c64(ops.to_nhwc(zprev.to(DEV)), w.to(DEV), b.to(DEV), scale.to(DEV) if xform else None, shift.to(DEV) if xform else None,
+                            want_stats=True)
+    assert rel_err(z.permute(0, 3, 1, 2).cpu(), ref) < 2e-5
+    s = stats.sum(dim=0).cpu()
+    assert torch.allclose(s[:, 0], ref.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(s[:, 1], (ref * ref).sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3)
+    z2, st2 = ops.conv_c64(ops.to_nhwc(zprev.to(DEV)), w.to(DEV), b.to(DEV), scale.to(DEV) if xform else None, shift.to(DEV) if xform else None,
+                           want_stats=True)
+    assert torch.equal(z, z2) and torch.equal(stats, st2)
+
+
 def test_conv_fused_input_transform_and_padding():
     """a = relu(z*scale+shift) applied while staging; zero padding must be applied AFTER the transform."""
     from object_detection_torch2_amd import ops
