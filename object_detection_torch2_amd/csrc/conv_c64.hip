@@ -14,6 +14,8 @@
 
 namespace {
 
+__host__ __device__ inline int64_t tiles_of(int N, int H, int W) { return ((int64_t)N * H * W + 31) / 32; }
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int C64_THREADS = 512, C64_WAVES = C64_THREADS / 64;     // 8 waves = 2 per SIMD; 16 would cap the kernel at 128 registers (it spills)
 constexpr int W_IMAGE = 9 * 2 * 8 * 64 * 4;          // floats of one 64-channel weight image (147,456 B)
@@ -52,8 +54,14 @@ __global__ __launch_bounds__(C64_THREADS) void conv_c64_kernel(const float* __re
     }
     __syncthreads();
     const int64_t M = (int64_t)N * H * W;
-    const int64_t tiles = (M + 31) / 32;
-    const int wave = group * C64_WAVES + (tid >> 6), nwaves = groups * C64_WAVES;
+    const int wave = group * C64_WAVES + (tid >> 6);
+    // a block owns a contiguous range of tiles and its 8 waves walk it side by side: the rows above / below a tile are re-read
+    // ~W/32 tiles later by the same CU, i.e. from its own L1 / its XCD's L2 (striding tiles over all waves of the grid made every
+    // XCD fetch its own copy of the three input rows: 2.4x the algorithmic HBM bytes)
+    const int64_t per_group = (tiles_of(N, H, W) + groups - 1) / groups;
+    const int64_t t_lo = (int64_t)group * per_group, t_hi = min(t_lo + per_group, tiles_of(N, H, W));
+    const int nwaves = C64_WAVES;
+    const int64_t first = t_lo + (tid >> 6);
     const float4* bl = reinterpret_cast<const float4*>(wl) + lane;             // + ((tap * 2 + j) * 8 + s4) * 64
     const float4* scl = reinterpret_cast<const float4*>(wl + W_IMAGE + 32 * half);
     const float4* shl = reinterpret_cast<const float4*>(wl + W_IMAGE + 64 + 32 * half);
@@ -84,8 +92,8 @@ __global__ __launch_bounds__(C64_THREADS) void conv_c64_kernel(const float* __re
 #pragma unroll
         for (int q = 0; q < 8; ++q) a[buf][q] = src[q];
     };
-    if (wave < tiles) { locate(wave); load_tap(0, 0); }
-    for (int64_t tile = wave; tile < tiles; tile += nwaves) {
+    if (first < t_hi) { locate(first); load_tap(0, 0); }
+    for (int64_t tile = first; tile < t_hi; tile += nwaves) {
         f32x16 acc[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -96,7 +104,7 @@ __global__ __launch_bounds__(C64_THREADS) void conv_c64_kernel(const float* __re
         for (int tap = 0; tap < 9; ++tap) {
             const int cur = (tap & 1);
             if (tap < 8) load_tap(tap + 1, cur ^ 1);
-            else if (tile + nwaves < tiles) { locate(tile + nwaves); load_tap(0, cur ^ 1); }   // 9 taps: tap 0 of the next tile lands in buffer 1 ...
+            else if (tile + nwaves < t_hi) { locate(tile + nwaves); load_tap(0, cur ^ 1); }   // 9 taps: tap 0 of the next tile lands in buffer 1 ...
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s4 = 0; s4 < 8; ++s4) {
