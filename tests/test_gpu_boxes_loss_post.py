@@ -178,3 +178,36 @@ def test_calc_iou(env, golden):
     pr = np.concatenate([np.clip(synth.logits(24, 2)[:, :500, :4] * 0.2 + 0.5, 0.01, None), np.zeros((2, 500, 21), np.float32)], 2)
     iou = utils.calc_iou(torch.from_numpy(pr).to(DEV), torch.from_numpy(t).to(DEV))
     assert np.array_equal(iou.cpu().numpy(), fx['iou_pr_gt'])          # bit-exact: pure fp32 +,-,*,/ in reference order
+
+
+def test_full_size_properties_of_loss_and_nms(env):
+    """Size-independent properties at the headline sizes (N = 32, P = 8732, C = 21), where the oracle is too slow to be the checker:
+    the loss does not depend on the order of the GT rows nor on extra zero padding rows; its gradient is zero on priors that are
+    neither selected positives nor mined negatives; NMS is idempotent and keeps a subset of the scored rows."""
+    synth, utils, net = env['synth'], env['utils'], env['net']
+    df = torch.from_numpy(env['df']).to(DEV)
+    out = torch.from_numpy(synth.logits(401, 32, loc_scale=0.3)).to(DEV).requires_grad_(True)
+    tg = synth.targets(402, 32, g_max=8)
+    base = net.loss(out, torch.from_numpy(tg).to(DEV), df)
+    base.backward()
+    g = out.grad.clone()
+    perm = tg[:, ::-1].copy()                                             # reversed GT rows (padding rows move to the front)
+    padded = np.concatenate([tg, np.zeros((32, 5, 25), np.float32)], axis=1)
+    for variant in (perm, padded):
+        # sums over matched GTs are re-associated when the rows move: a few ulp on a value of ~15
+        assert abs(net.loss(out.detach(), torch.from_numpy(variant).to(DEV), df).item() - base.item()) < 1e-4
+    touched = (g.abs().sum(dim=2) > 0).sum(dim=1)                         # priors with any gradient, per image
+    match = net._match(torch.from_numpy(tg).to(DEV), df).any(dim=2).sum(dim=1)
+    assert (touched <= 4 * match + 1).all() and (touched >= match.clamp(max=1)).all()   # positives + at most 3:1 negatives
+    scored = torch.from_numpy(synth.logits(403, 32, void_bias=3.0, loc_scale=0.3)).to(DEV)
+    utils.decode_score_(scored, df)
+    before = scored.clone()
+    _, keep1 = utils.non_maximum_suppression(scored, return_keep=True)
+    after1 = scored.clone()
+    _, keep2 = utils.non_maximum_suppression(scored, return_keep=True)
+    assert torch.equal(keep1, keep2) and torch.equal(scored, after1)      # idempotent
+    assert torch.equal(after1[:, :, :4], before[:, :, :4])
+    k = keep1.bool()
+    assert torch.equal(after1[k], before[k]) and (after1[~k][:, 4:] == 0).all()
+    cand = (before[:, :, 5:].max(dim=2).values > 0)
+    assert (k & ~cand).sum() == 0 and (k.sum(dim=1) > 0).all() and (k.sum(dim=1) < cand.sum(dim=1)).all()
