@@ -193,11 +193,11 @@ def main():
                     avg_launch_ms=round(a['ms'] / a['n'], 4), layers=sorted(a['layers']),
                     conv_fwd_tflops_launches_over_10_gflop=round(sum(v['flops'] for v in agg.values()) / (sum(v['ms'] for v in agg.values()) * 1e-3) / 1e12, 2))
         if not eng.single_stream:
-            # In the timed region the backbone stream co-runs with two other streams, and an event pair on it also spans the time
-            # the command processor spends dispatching the other queues: 0.89 ms between the events for a kernel whose own
-            # duration (rocprofv3 --kernel-trace of this same command, profiles/r01_o_*) is 0.66-0.72 ms.  So the figure that
-            # rocprofv3 can confirm is taken over three more steps with the streams serialised (same launches, same order per
-            # stream); the timed-region event figures stay in the line as `timed_region`.
+            # In the timed region the backbone stream shares the chip with two other streams, so an event pair on it measures a
+            # time-share: 0.89 ms per launch for a kernel whose own duration (rocprofv3 --kernel-trace of this same command,
+            # profiles/r01_o_*) is 0.66-0.72 ms.  So the figure that rocprofv3 can confirm is taken over three more steps with
+            # the streams serialised (same launches, same order per stream); the timed-region event figures stay in the line
+            # as `timed_region`.
             eng.single_stream = True
             eng.prof = []
             for _ in range(3):
@@ -208,7 +208,7 @@ def main():
             if ex:
                 ach_x = ex['flops'] / (ex['ms'] * 1e-3) / 1e12
                 roof['timed_region'] = dict(achieved=roof['achieved'], frac=roof['frac'], avg_launch_ms=roof['avg_launch_ms'], launches=roof['launches'],
-                                            what='HIP events around the launches inside the timed region: includes queue arbitration between the three co-running streams')
+                                            what='HIP events around the launches inside the timed region, where three streams share the chip (a time-share, not the kernel alone)')
                 roof.update(achieved=round(ach_x, 2), frac=round(ach_x / FP32_MFMA_PEAK_TFLOPS, 4), avg_launch_ms=round(ex['ms'] / ex['n'], 4), launches=ex['n'],
                             measured='HIP events around the same launches over 3 extra steps right after the timed region, streams serialised '
                                      '(agrees with the per-dispatch durations rocprofv3 reports for this command)')
