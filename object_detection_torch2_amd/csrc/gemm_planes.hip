@@ -37,14 +37,18 @@ struct PlaneArgs {
 template <int BM, int BN>
 struct PlaneWaves { static constexpr int value = (BM + BN == 256) ? 2 : 3; };
 
-template <int BM, int BN, int ABL = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, PlaneWaves<BM, BN>::value))) void gemm_planes_dma_kernel(PlaneArgs a) {
-    constexpr int WROWS = BM / 2, WCOLS = BN / 2, MT = WROWS / 32, NT = WCOLS / 32, AL = BM / 32, BL = BN / 32;
+// NW = 4: 2 x 2 waves of (BM/2) x (BN/2); NW = 8: 2 x 4 waves of (BM/2) x (BN/4) on the same block tile (twice the waves per SIMD for the
+// same LDS footprint: more latency cover for the barrier and the DMA stream, 1.25x the LDS fragment reads)
+template <int BM, int BN, int ABL = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, PlaneWaves<BM, BN>::value * NW / 4))) void gemm_planes_dma_kernel(PlaneArgs a) {
+    constexpr int WNC = NW / 2;                                    // waves along n
+    constexpr int RPP = 8 * NW;                                    // operand rows one DMA pass of the block covers
+    constexpr int WROWS = BM / 2, WCOLS = BN / WNC, MT = WROWS / 32, NT = WCOLS / 32, AL = BM / RPP, BL = BN / RPP;
     __shared__ __attribute__((aligned(1024))) float lds[2 * (BM + BN) * LROW];
     float* As = lds;
     float* Bs = lds + 2 * BM * LROW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WNC, wn = wave % WNC;
 
     int t;
     {
@@ -73,12 +77,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, PlaneWav
         const unsigned kb = (unsigned)ld_kt * (BK * 4);
 #pragma unroll
         for (int i = 0; i < AL; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(vb + (a_off + (unsigned)(32 * i) * rowK + kb)),
-                                             (lptr_t)(a_dst + (buf * BM + 32 * i) * LROW), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(vb + (a_off + (unsigned)(RPP * i) * rowK + kb)),
+                                             (lptr_t)(a_dst + (buf * BM + RPP * i) * LROW), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < BL; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(ub + (b_off + (unsigned)(32 * i) * rowK + kb)),
-                                             (lptr_t)(b_dst + (buf * BN + 32 * i) * LROW), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(ub + (b_off + (unsigned)(RPP * i) * rowK + kb)),
+                                             (lptr_t)(b_dst + (buf * BN + RPP * i) * LROW), 16, 0, 0);
         if (++ld_kt == a.KT) {
             if (ld_tile + 1 < ntl) {
                 ld_kt = 0; ++ld_tile;
@@ -185,9 +189,10 @@ int ssdhip_gemm_planes_dma(const float* v, const float* u, float* y, int M, int 
     a.M = M; a.K = K; a.KT = K / BK; a.Cout = Cout; a.rows_per_plane = rows_per_plane;
     a.MB = M / BM; a.NB = cdiv(Cout, BN); a.tpb = tpb;
     dim3 grid(cdiv(a.MB, a.tpb) * a.NB), block(256);
-    if (abl == 1) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128, 1>), grid, block, 0, st, a);
+    if (abl == 4) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128, 0, 4>), grid, block, 0, st, a);      // A/B: the 4-wave block
+    else if (abl == 1) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128, 1>), grid, block, 0, st, a);
     else if (abl == 2) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128, 2>), grid, block, 0, st, a);
-    else if (BM == 128 && BN == 128) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128>), grid, block, 0, st, a);
+    else if (BM == 128 && BN == 128) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128, 0, 8>), grid, dim3(512), 0, st, a);   // 8 waves: +3 % (scripts/plane_gemm_probe.py)
     else if (BM == 128 && BN == 64) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 64>), grid, block, 0, st, a);
     else if (BM == 64 && BN == 128) hipLaunchKernelGGL((gemm_planes_dma_kernel<64, 128>), grid, block, 0, st, a);
     else return SSDHIP_ENOSUP;
