@@ -6,7 +6,7 @@ import torch
 from object_detection_torch2_amd import _lib
 DEV = 'cuda:0'
 lib = _lib.load()
-SHAPES = [('conv_4_2', 11648, 512, 512), ('conv_3_2', 46208, 256, 256), ('conv_4_1', 11648, 256, 512), ('conv_5_x', 3200, 512, 512), ('conv_6_1', 3200, 512, 1024)]
+SHAPES = [('conv_2_2', 180224, 128, 128), ('conv_3_1', 45056, 128, 256), ('conv_4_2', 11648, 512, 512), ('conv_3_2', 46208, 256, 256), ('conv_4_1', 11648, 256, 512), ('conv_5_x', 3200, 512, 512), ('conv_6_1', 3200, 512, 1024)]
 codes = [int(c) for c in sys.argv[1:]] or [128128, 7128128, 6128128, 5128128, 40128128, 41128128, 43128128, 45128128, 47128128]
 def run(p, st):
     return lib.ssdhip_conv2d_nhwc(ctypes.byref(p), st)
