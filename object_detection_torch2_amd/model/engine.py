@@ -366,7 +366,7 @@ class Engine:
         # launches that cannot fill the chip).  Only two backbone outputs have consumers outside the backbone stream -- the inputs
         # of det_4_3 and of conv_6_1 (forward and weight gradient): those stages wait for the events their readers leave in _readers.
         bb = None if (self.single_stream or self.tail_start == 0) else self._side_stream(dev, which=2)
-        entry = main.record_event()
+        entry = main.record_event() if fork.side_stream is not None else None
         if fork.side_stream is not None:
             fork.side_stream.wait_event(entry)               # `out` may reuse memory that step i's loss kernels still read
         if bb is not None:

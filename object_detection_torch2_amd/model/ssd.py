@@ -209,6 +209,40 @@ class SSD(nn.Module):
             return _SSDForward.apply(self, x, *params)
         return self._engine().forward(x, save=False, ready_event=ready_event)
 
+    def graphed_forward(self, example: torch.Tensor):
+        """Extension: capture `forward` for inputs shaped like `example` in a HIP graph (inference, no autograd) and return
+        `run(x) -> outputs`: ≈90 launches with their cross-stream events become one.  Measured (scripts/graph_latency.py): no
+        throughput gain at batch 2-8 -- eager launches are asynchronous and the device time (1.8 ms at batch 2) exceeds the
+        host's enqueue time -- so this is for callers whose host thread is the bottleneck.  `outputs` is the graph's static output tensor (overwritten by the next call); parameters are read at replay
+        time, so weight updates made with stock torch ops are seen, but call this again after `load_state_dict` or an optimizer
+        step that repacks weights (`hip_weights_changed`)."""
+        _lib.require_gpu(example)
+        static_in = _lib.f32c(example).clone()
+        eng = self._engine()
+        with torch.no_grad():
+            warm = torch.cuda.Stream(device=example.device)
+            warm.wait_stream(torch.cuda.current_stream(example.device))
+            with torch.cuda.stream(warm):
+                for _ in range(2):                   # lazy buffers, packed weights, kernel attributes
+                    eng.forward(static_in, save=False)
+            torch.cuda.current_stream(example.device).wait_stream(warm)
+            torch.cuda.synchronize(example.device)
+            eng._readers.clear()                     # events of the eager warm-up must not be waited on inside the capture
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = eng.forward(static_in, save=False)
+            eng._readers.clear()
+
+        def run(x: torch.Tensor) -> torch.Tensor:
+            if tuple(x.shape) != tuple(static_in.shape):
+                raise ValueError(f'graphed_forward was captured for {tuple(static_in.shape)}, got {tuple(x.shape)}')
+            static_in.copy_(x)
+            graph.replay()
+            return static_out
+
+        run.graph = graph
+        return run
+
     def finetune_backbone(self, enable: bool = True):
         """Extension: un-freeze the VGG16-bn backbone.  The reference never does (ssd.py:31-32; 72.2 -> 187.9
         GFLOP per image); train_params() then yields every feature parameter, in module order, before the detectors."""

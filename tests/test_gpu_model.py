@@ -284,3 +284,55 @@ def test_stream_pipelining_is_bit_identical_to_single_stream(env):
         assert torch.equal(y0, y1)
         for k in s0:
             assert torch.equal(s0[k], s1[k]), k
+
+
+@pytest.mark.parametrize('single', [True, False])
+def test_forward_is_graph_capturable(env, single):
+    """The C-ABI calls take a stream, allocate nothing and never synchronise the host, so a whole forward -- serialised, or with
+    its side and backbone streams forked from and joined into the capturing stream -- can be captured once in a HIP graph and
+    replayed on new input data with identical results."""
+    synth = env['synth']
+    net = make_net(env)
+    net._engine().single_stream = single
+    x = torch.from_numpy(synth.images(700, 2)).to(DEV)
+    side = torch.cuda.Stream()
+    with torch.no_grad():
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                net(x)                                   # warm-up: lazy buffers, packed weights, LDS attributes
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        net._engine()._readers.clear()                   # events of the eager warm-up must not be waited on inside the capture
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            y = net(x)
+        net._engine()._readers.clear()
+        for seed in (701, 702):
+            new = torch.from_numpy(synth.images(seed, 2)).to(DEV)
+            x.copy_(new)
+            graph.replay()
+            got = y.clone()
+            torch.cuda.synchronize()
+            want = net(new)
+            assert torch.equal(got, want)
+            torch.cuda.synchronize()
+            net._engine()._readers.clear()
+
+
+def test_graphed_forward_api(env):
+    synth = env['synth']
+    net = make_net(env)
+    run = net.graphed_forward(torch.from_numpy(synth.images(710, 2)).to(DEV))
+    for seed in (711, 712):
+        x = torch.from_numpy(synth.images(seed, 2)).to(DEV)
+        got = run(x).clone()
+        torch.cuda.synchronize()
+        net._engine()._readers.clear()
+        with torch.no_grad():
+            want = net(x)
+        assert torch.equal(got, want)
+        torch.cuda.synchronize()
+        net._engine()._readers.clear()
+    with pytest.raises(ValueError):
+        run(torch.zeros(3, 3, 300, 300, device=DEV))
