@@ -146,6 +146,9 @@ int ssdhip_nms(float* outputs, int N, int P, int C, float iou_thresh, uint8_t* k
  * CU per image busy).                                                                                        */
 int64_t ssdhip_nms_ws_bytes(int N, int P);
 int ssdhip_nms_ws(float* outputs, int N, int P, int C, float iou_thresh, uint8_t* keep, void* ws, void* stream);
+/* option named by the north star ("per-class NMS"), not the reference's behaviour (utils.py:99-109 is class-agnostic): a box is
+ * suppressed only by a kept box of the same arg-max class; same workspace, same kernels with one extra compare.              */
+int ssdhip_nms_ws_per_class(float* outputs, int N, int P, int C, float iou_thresh, uint8_t* keep, void* ws, void* stream);
 
 /* ---- backward of the trainable tail (autograd of model/ssd.py:49-77 layers; train.py:121) ---------------- */
 /* wgrad: dW (Cout,R,S,Cin)->written in OIHW state_dict layout, db (Cout) optional.

@@ -62,6 +62,7 @@ SIGNATURES = {
     'ssdhip_nms': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     'ssdhip_nms_ws_bytes': (c_int64, [c_int, c_int]),
     'ssdhip_nms_ws': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    'ssdhip_nms_ws_per_class': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     'ssdhip_conv2d_wgrad_ws_bytes': (c_int64, [POINTER(WgradParams)]),
     'ssdhip_conv2d_wgrad': (c_int, [POINTER(WgradParams), c_void_p]),
     'ssdhip_conv2d_wgrad_winograd_ws_bytes': (c_int64, [POINTER(WgradParams)]),

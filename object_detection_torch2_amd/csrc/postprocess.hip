@@ -220,6 +220,14 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(float* __restrict__ ou
 //   nms_scan_kernel   per image: wave 0 walks the sorted candidates; `removed` bits live in registers (3 words per lane),
 //                     rows are prefetched 4 ahead; kept rows are scattered to a flag array, then the block zeroes the
 //                     score columns of every prior that is not kept (utils.py:114)
+__device__ __forceinline__ int argmax_class(const float* row, int ROW) {      // first maximum of the non-void score columns
+    int best = 5;
+    float sc = row[5];
+    for (int c = 6; c < ROW; ++c)
+        if (row[c] > sc) { sc = row[c]; best = c; }
+    return best;
+}
+
 struct NmsWs {
     int* count;            // (N)
     int* sidx;             // (N, P) sorted prior indices
@@ -227,7 +235,8 @@ struct NmsWs {
     unsigned char* flag;   // (N, P) keep flags by prior index
     unsigned long long* mask;   // (N, P, W) W = ceil(P / 64)
     unsigned long long* keys;   // (N, sortcap) sort keys in global memory, large-P variant only (P > NMS_WS_SMALL_P)
-    int W, sortcap;
+    int* scls;             // (N, P) class (arg-max score column) of the sorted candidates, read by the per-class option
+    int W, sortcap, per_class;
 };
 
 __global__ __launch_bounds__(NMS_THREADS) void nms_sort_kernel(const float* __restrict__ outputs, int P, int C, NmsWs ws) {
@@ -273,6 +282,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sort_kernel(const float* __re
         const float* row = out + (size_t)idx * ROW;
         ws.sidx[(size_t)n * P + i] = idx;
         ws.sbox[(size_t)n * P + i] = make_float4(row[0], row[1], row[2], row[3]);
+        ws.scls[(size_t)n * P + i] = argmax_class(row, ROW);
     }
 }
 
@@ -287,12 +297,15 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(int P, float thr, NmsWs w
     const bool jv = j < K;
     const float4 bj = jv ? sb[j] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 bi = (i0 + lane < K) ? sb[i0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int* sc = ws.scls + (size_t)n * P;
+    const int cj = (ws.per_class && jv) ? sc[j] : 0, ci = (ws.per_class && i0 + lane < K) ? sc[i0 + lane] : 0;
     unsigned long long mine = 0ull;
 #pragma unroll 8
     for (int r = 0; r < 64; ++r) {
         float4 hb;
         hb.x = __shfl(bi.x, r, 64); hb.y = __shfl(bi.y, r, 64); hb.z = __shfl(bi.z, r, 64); hb.w = __shfl(bi.w, r, 64);
-        const bool hit = jv && (j > i0 + r) && iou_gt(hb, bj, thr);
+        const bool same = !ws.per_class || __shfl(ci, r, 64) == cj;       // per-class option: only same-class boxes suppress each other
+        const bool hit = jv && (j > i0 + r) && same && iou_gt(hb, bj, thr);
         const unsigned long long m = __ballot(hit);
         if (lane == r) mine = m;
     }
@@ -464,6 +477,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sort_big_kernel(const float* 
         const float* row = out + (size_t)idx * ROW;
         ws.sidx[(size_t)n * P + i] = idx;
         ws.sbox[(size_t)n * P + i] = make_float4(row[0], row[1], row[2], row[3]);
+        ws.scls[(size_t)n * P + i] = argmax_class(row, ROW);
     }
 }
 
@@ -527,7 +541,9 @@ size_t nms_ws_layout(int N, int P, NmsWs* ws, unsigned char* base) {
     int sortcap = 0;
     if (P > NMS_WS_SMALL_P) { sortcap = 64; while (sortcap < P) sortcap <<= 1; }
     const size_t o_keys = take((size_t)N * sortcap * 8);
+    const size_t o_scls = take((size_t)N * P * 4);
     if (ws) {
+        ws->scls = reinterpret_cast<int*>(base + o_scls); ws->per_class = 0;
         ws->keys = reinterpret_cast<unsigned long long*>(base + o_keys); ws->sortcap = sortcap;
         ws->count = reinterpret_cast<int*>(base + o_count); ws->sidx = reinterpret_cast<int*>(base + o_sidx);
         ws->sbox = reinterpret_cast<float4*>(base + o_sbox); ws->flag = base + o_flag;
@@ -562,7 +578,7 @@ int64_t ssdhip_nms_ws_bytes(int N, int P) {
     return (int64_t)nms_ws_layout(N, P, nullptr, nullptr);
 }
 
-int ssdhip_nms_ws(float* outputs, int N, int P, int C, float iou_thresh, uint8_t* keep, void* ws_ptr, void* stream) {
+static int nms_ws_impl(float* outputs, int N, int P, int C, float iou_thresh, uint8_t* keep, void* ws_ptr, void* stream, int per_class) {
     SSDHIP_REQUIRE(outputs && ws_ptr && N > 0 && P > 0 && C >= 2, "nms_ws: bad arguments");
     SSDHIP_REQUIRE(P <= NMS_WS_MAX_P, "nms_ws: P <= 32768");
     SSDHIP_REQUIRE(N <= 65535, "nms_ws: N <= 65535");
@@ -581,6 +597,7 @@ int ssdhip_nms_ws(float* outputs, int N, int P, int C, float iou_thresh, uint8_t
     }
     NmsWs ws;
     nms_ws_layout(N, P, &ws, reinterpret_cast<unsigned char*>(ws_ptr));
+    ws.per_class = per_class;
     hipStream_t st = (hipStream_t)stream;
     const int chunks = (P + 63) / 64;
     if (P <= NMS_WS_SMALL_P) {      // two 64-row batches of the bit-matrix fit 160 KiB of LDS; 192 word-pair loaders
@@ -601,6 +618,14 @@ int ssdhip_nms_ws(float* outputs, int N, int P, int C, float iou_thresh, uint8_t
         SSDHIP_CHECK_LAUNCH();
     }
     return SSDHIP_OK;
+}
+
+int ssdhip_nms_ws(float* outputs, int N, int P, int C, float iou_thresh, uint8_t* keep, void* ws_ptr, void* stream) {
+    return nms_ws_impl(outputs, N, P, C, iou_thresh, keep, ws_ptr, stream, 0);
+}
+
+int ssdhip_nms_ws_per_class(float* outputs, int N, int P, int C, float iou_thresh, uint8_t* keep, void* ws_ptr, void* stream) {
+    return nms_ws_impl(outputs, N, P, C, iou_thresh, keep, ws_ptr, stream, 1);
 }
 
 int ssdhip_nms(float* outputs, int N, int P, int C, float iou_thresh, uint8_t* keep, void* stream) {

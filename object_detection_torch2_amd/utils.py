@@ -78,11 +78,13 @@ def calc_iou(t: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
 _nms_ws = {}
 
 
-def non_maximum_suppression(outputs: torch.Tensor, iou_thresh: float = 0.5, return_keep: bool = False, variant: str = 'auto') -> torch.Tensor:
+def non_maximum_suppression(outputs: torch.Tensor, iou_thresh: float = 0.5, return_keep: bool = False, variant: str = 'auto',
+                            per_class: bool = False) -> torch.Tensor:
     """utils.py:80-116: greedy class-agnostic NMS; zeroes outputs[:, :, 4:] of suppressed / void rows IN PLACE and
     returns `outputs` (the same object), like the reference.
     variant: 'lds' (one workgroup per image, everything in LDS), 'ws' (bit-matrix over the whole chip + serial scan,
-    cached workspace; P <= 32768) or 'auto' (= ws)."""
+    cached workspace; P <= 32768) or 'auto' (= ws).
+    per_class (extension, default off = the reference's class-agnostic rule): boxes only suppress boxes of the same class."""
     _lib.require_gpu(outputs)
     if outputs.dim() != 3 or outputs.shape[2] < 6:
         raise ValueError(f'expected (N, P, 4 + C) with C >= 2, got {tuple(outputs.shape)}')
@@ -97,8 +99,11 @@ def non_maximum_suppression(outputs: torch.Tensor, iou_thresh: float = 0.5, retu
             ws = torch.empty(lib.ssdhip_nms_ws_bytes(N, P), dtype=torch.uint8, device=work.device)
             _nms_ws.clear()
             _nms_ws[key] = ws
-        _lib.check(lib.ssdhip_nms_ws(_lib.ptr(work), N, P, row - 4, float(iou_thresh), _lib.ptr(keep), _lib.ptr(ws), _lib.stream()), 'nms')
+        fn = lib.ssdhip_nms_ws_per_class if per_class else lib.ssdhip_nms_ws
+        _lib.check(fn(_lib.ptr(work), N, P, row - 4, float(iou_thresh), _lib.ptr(keep), _lib.ptr(ws), _lib.stream()), 'nms')
     else:
+        if per_class:
+            raise ValueError("per_class NMS runs on the workspace variant (variant='ws' or 'auto')")
         _lib.check(lib.ssdhip_nms(_lib.ptr(work), N, P, row - 4, float(iou_thresh), _lib.ptr(keep), _lib.stream()), 'nms')
     if work is not outputs:
         outputs.copy_(work)

@@ -263,19 +263,24 @@ def calc_iou(t, s):
         return np.where(inter > 0, inter / (t[..., 2] * t[..., 3] + s[..., 2] * s[..., 3] - inter), inter)
 
 
-def nms_keep(output, iou_thresh=0.5):
+def nms_keep(output, iou_thresh=0.5, per_class=False):
     """Greedy class-agnostic NMS keep list for one image (P,4+C), utils.py:90-109.
-    Candidates: rows with max(cols 5:) > 0, sorted by that score descending, ties by lower index."""
+    Candidates: rows with max(cols 5:) > 0, sorted by that score descending, ties by lower index.
+    per_class (north-star option, not the reference): only boxes of the same arg-max class suppress each other."""
     score = output[:, 5:].max(axis=1)
     order = np.argsort(-score.astype(np.float64), kind='stable')
     order = order[score[order] > 0]
     boxes = output[order, :4].astype(f32)
+    cls = output[order, 5:].argmax(axis=1)
     alive = np.ones(len(order), bool)
     for i in range(len(order)):
         if not alive[i] or i + 1 >= len(order):
             continue
         iou = calc_iou(boxes[None, i:i + 1], boxes[None, i + 1:])[0, 0]
-        alive[i + 1:] &= ~(iou > f32(iou_thresh))
+        hit = iou > f32(iou_thresh)
+        if per_class:
+            hit &= cls[i + 1:] == cls[i]
+        alive[i + 1:] &= ~hit
     return order[alive]
 
 

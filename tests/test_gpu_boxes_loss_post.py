@@ -211,3 +211,23 @@ def test_full_size_properties_of_loss_and_nms(env):
     assert torch.equal(after1[k], before[k]) and (after1[~k][:, 4:] == 0).all()
     cand = (before[:, :, 5:].max(dim=2).values > 0)
     assert (k & ~cand).sum() == 0 and (k.sum(dim=1) > 0).all() and (k.sum(dim=1) < cand.sum(dim=1)).all()
+
+
+@pytest.mark.parametrize('bias,seed', [(3.0, 31), (0.0, 32)])
+def test_per_class_nms_option(env, bias, seed):
+    """North-star option (the reference is class-agnostic): same kernels, suppression only inside a class; keep set vs the oracle."""
+    O, synth, utils = env['O'], env['synth'], env['utils']
+    raw = synth.logits(seed, 2, void_bias=bias, loc_scale=0.3)
+    pre = np.concatenate([O.calc_coordicate(raw, env['df']), O.calc_score(raw)], axis=2)
+    t = torch.from_numpy(pre).to(DEV)
+    _, keep = utils.non_maximum_suppression(t, return_keep=True, per_class=True)
+    _, keep_agn = utils.non_maximum_suppression(torch.from_numpy(pre).to(DEV), return_keep=True)
+    for n in range(2):
+        want = np.zeros(8732, dtype=bool)
+        want[O.nms_keep(pre[n], per_class=True)] = True
+        assert np.array_equal(keep[n].cpu().numpy().astype(bool), want)
+    # not a superset of the class-agnostic keep set in general (a box that survives here may suppress one that was kept there),
+    # but fewer pairs can suppress each other, so more boxes survive on this input
+    assert keep.sum() > keep_agn.sum()
+    with pytest.raises(ValueError):
+        utils.non_maximum_suppression(torch.from_numpy(pre).to(DEV), variant='lds', per_class=True)
