@@ -442,6 +442,9 @@ class Engine:
                     bm = self._conv(c, cur, cur_xs, z.data_ptr(), g['ho'] * g['wo'] * c.cout, N, g['hi'], g['wi'], g['ho'], g['wo'],
                                     ws['partial'] if training else None)
                     rows = (M + bm - 1) // bm
+                if training and rows * c.cout * 2 > ws['partial'].numel():
+                    # the kernels cannot check this themselves; an undersized table once corrupted its neighbours silently
+                    raise RuntimeError(f'{c.name}: {rows} BatchNorm partial rows do not fit the workspace ({ws["partial"].numel()} floats)')
                 if bb is not None and i == self.tail_start:
                     self._note_reader(i - 1, main.record_event())     # the backbone's last activation is consumed
                 if training:

@@ -336,3 +336,19 @@ def test_graphed_forward_api(env):
         net._engine()._readers.clear()
     with pytest.raises(ValueError):
         run(torch.zeros(3, 3, 300, 300, device=DEV))
+
+
+@pytest.mark.parametrize('N,S', [(3, 299), (2, 301), (5, 267), (2, 333)])
+def test_odd_input_sizes_forward_and_backward(env, N, S):
+    """Odd maps everywhere (2x2 Winograd tiles and pools overhang the map): outputs vs the oracle, workspace guards silent."""
+    O, synth = env['O'], env['synth']
+    net = make_net(env)
+    x = synth.images(800 + S, N, S)
+    sd = O.init_state(seed=1)
+    with torch.no_grad():
+        ref = O.forward(sd, torch.from_numpy(x), training=True)
+    out = net(torch.from_numpy(x).to(DEV))
+    assert tuple(out.shape) == tuple(ref.shape)
+    assert np.abs(out.detach().cpu().numpy() - ref.numpy()).max() < 3e-3
+    out.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in net.train_params())
