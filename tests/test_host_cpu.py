@@ -114,3 +114,27 @@ def test_average_precision_matches_reference_and_voc(golden):
     # TP assignment: two predictions claim GT 0, only the first (higher score) is a TP; the third matches nothing
     iou = torch.tensor([[0.9, 0.1], [0.8, 0.2], [0.3, 0.4]])
     assert E.assign_true_positives(iou).view(-1).tolist() == [1.0, 0.0, 0.0]
+
+
+def test_plain_c_program_links_against_the_library(tmp_path):
+    """The boundary is a C ABI: a C99 translation unit that includes include/ssdhip.h links against libssdhip.so and calls it
+    (version query and an argument error with its message: no GPU needed)."""
+    import subprocess
+    src = tmp_path / 'client.c'
+    src.write_text(f'''
+#include <stdio.h>
+#include <string.h>
+#include "{ROOT}/include/ssdhip.h"
+int main(void) {{
+    ssdhip_conv_params p;
+    memset(&p, 0, sizeof p);
+    int rc = ssdhip_conv2d_nhwc(&p, NULL);              /* null pointers: must be rejected before any launch */
+    printf("%d %d %s\\n", ssdhip_version(), rc, ssdhip_last_error());
+    return 0;
+}}
+''')
+    exe = tmp_path / 'client'
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Werror', str(src), '-o', str(exe), f'-L{libdir}', '-lssdhip', f'-Wl,-rpath,{libdir}'], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split(maxsplit=2)
+    assert int(out[0]) >= 100 and int(out[1]) < 0 and 'null pointer' in out[2]
