@@ -533,6 +533,14 @@ class Engine:
                 fn = self.lib.ssdhip_conv2d_wgrad_winograd_ws_bytes if self._wgrad_wino(spec, hi, wi) else self.lib.ssdhip_conv2d_wgrad_ws_bytes
                 ws_bytes = max(ws_bytes, _lib.check(fn(ctypes.byref(p)), 'wgrad_ws_bytes'))
         bw['wgrad_ws'] = torch.empty((ws_bytes + 3) // 4, **f)
+        dg_v = dg_m = 0             # Winograd data gradients (un-frozen backbone): dy planes V and dx planes M
+        for i in range(self.tail_start + 1, len(self.stages)):
+            s, g = self.stages[i], geo[i]
+            if self._dgrad_wino(s.conv, g):
+                tp = (N * ((g['ho'] + 1) // 2) * ((g['wo'] + 1) // 2) + 127) // 128 * 128
+                dg_v, dg_m = max(dg_v, 16 * tp * s.conv.cout), max(dg_m, 16 * tp * s.conv.cin)
+        bw['dg_v'] = torch.empty(dg_v, **f) if dg_v else None
+        bw['dg_m'] = torch.empty(dg_m, **f) if dg_m else None
         b['bwd'] = bw
         return bw
 
@@ -565,6 +573,39 @@ class Engine:
         p.ws = bw['wgrad_ws'].data_ptr()
         fn = self.lib.ssdhip_conv2d_wgrad_winograd if self._wgrad_wino(spec, hi, wi) else self.lib.ssdhip_conv2d_wgrad
         _lib.check(fn(ctypes.byref(p), _lib.stream()), f'wgrad {spec.name}')
+
+    def _dgrad_wino(self, spec, g):
+        """Data gradient of a 3x3/s1/p1 layer = the same convolution of dy with the flipped, transposed filter: it runs through the
+        forward's Winograd pipeline where that pays (the un-frozen backbone's 75x75 .. 19x19 layers; the tail's maps are too small)."""
+        return (self.m._tune_all and not self.bf16 and not spec.is_head and spec.k == 3 and spec.stride == 1 and spec.pad == 1
+                and spec.cout % 32 == 0 and spec.cout >= 128 and spec.cin % 4 == 0 and 256 % (spec.cin // 4) == 0 and spec.cin >= 64
+                and 19 <= g['hi'] <= 160 and 19 <= g['wi'] <= 160)
+
+    def _dgrad_winograd(self, spec, dy, dx, bw, N, h, w):
+        L, st = self.lib, _lib.stream()
+        wt, _ = self._weight(spec)
+        key = (wt.data_ptr(), wt._version, self.m._hip_epoch)
+        rows = _rup(spec.cin, 128)
+        if getattr(spec, 'dg_u', None) is None or spec.dg_u.device != wt.device:
+            spec.dg_u = torch.empty(16 * rows * spec.cout, device=wt.device, dtype=torch.float32)
+            spec.dg_key = None
+        if spec.dg_key != key:
+            flipped = wt.detach().flip(2, 3).transpose(0, 1).contiguous()          # (Cin, Cout, 3, 3): filter of the adjoint convolution
+            _lib.check(L.ssdhip_winograd_weight(_lib.ptr(flipped), _lib.ptr(spec.dg_u), spec.cin, spec.cout, rows, spec.cout, st), 'winograd_weight (dgrad)')
+            spec.dg_key = key
+        V, Mo = bw['dg_v'], bw['dg_m']
+        tp = (N * ((h + 1) // 2) * ((w + 1) // 2) + 127) // 128 * 128
+        _lib.check(L.ssdhip_winograd_input(_lib.ptr(dy), None, None, _lib.ptr(V), N, h, w, spec.cout, st), f'winograd_input (dgrad {spec.name})')
+        p = _lib.ConvParams()
+        p.x, p.w, p.y, p.y_batch_stride = V.data_ptr(), spec.dg_u.data_ptr(), Mo.data_ptr(), tp * spec.cin
+        p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout = 16, 1, tp, spec.cout, 1, tp, spec.cin
+        p.R, p.S, p.stride, p.pad, p.KP, p.mode, p.accumulate = 1, 1, 1, 0, spec.cout, 0, 0
+        p.tile = 128128 if (16 * tp // 128) * ((spec.cin + 127) // 128) > 2000 else 64128
+        if spec.cin < 128:
+            p.tile = 128064
+        p.rows_per_img, p.w_img_stride = tp, rows * spec.cout
+        _lib.check(L.ssdhip_conv2d_nhwc(ctypes.byref(p), st), f'winograd gemm (dgrad {spec.name})')
+        _lib.check(L.ssdhip_winograd_output(_lib.ptr(Mo), None, _lib.ptr(dx), None, N, h, w, spec.cin, st), f'winograd_output (dgrad {spec.name})')
 
     def _dgrad(self, spec, dy, dx, N, hdy, wdy, hin, win, accumulate):
         w = self._pack(spec, dgrad=True)
@@ -651,10 +692,12 @@ class Engine:
                 self._note_reader(i - 1, fork.mark())   # conv_6_1's weight gradient reads the backbone's last activation
             if i > self.tail_start:
                 prev, gp = self.stages[i - 1], geo[i - 1]
-                if prev.pool_pad is None:
-                    self._dgrad(c, dz, bw['da'][i - 1], N, g['ho'], g['wo'], g['hi'], g['wi'], accumulate=False)
-                else:       # un-frozen backbone only: gradient of the pooled map, then through BN.ReLU.MaxPool to the pre-pool map
-                    self._dgrad(c, dz, bw['dpool'][i - 1], N, g['ho'], g['wo'], g['hi'], g['wi'], accumulate=False)
+                target = bw['da'][i - 1] if prev.pool_pad is None else bw['dpool'][i - 1]
+                if self._dgrad_wino(c, g) and bw['dg_v'] is not None:
+                    self._dgrad_winograd(c, dz, target, bw, N, g['hi'], g['wi'])
+                else:
+                    self._dgrad(c, dz, target, N, g['ho'], g['wo'], g['hi'], g['wi'], accumulate=False)
+                if prev.pool_pad is not None:       # un-frozen backbone only: gradient of the pooled map, then through BN.ReLU.MaxPool
                     pst = self._bn[prev.bn_name]
                     _lib.check(L.ssdhip_bn_relu_pool_bwd(_lib.ptr(b['z'][i - 1]), _lib.ptr(pst['scale']), _lib.ptr(pst['shift']),
                                                          _lib.ptr(bw['dpool'][i - 1]), _lib.ptr(bw['da'][i - 1]), N, gp['ho'], gp['wo'],
