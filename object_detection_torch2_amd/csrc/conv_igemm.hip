@@ -527,7 +527,7 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
         if (a.tpb > 8) a.tpb = 8;
         // plain row-major planes: stage with the LDS-DMA engine (gemm_planes.hip) unless tile code 9xxxxxx asks for the
         // register-staged kernel (A/B comparison in scripts/wino_bench.py)
-        if (p->tile / 1000000 != 9 && !(BM == 64 && BN == 64) && p->KP == p->Cin && p->Cin % BK == 0 && p->Cin >= 256) {   // K = 128: register staging measured faster
+        if (p->tile / 1000000 != 9 && !(BM == 64 && BN == 64) && p->KP == p->Cin && p->Cin % BK == 0 && (p->Cin >= 256 || (p->Cin == 128 && BM == 128 && BN == 128))) {   // other K = 128 tiles: register staging measured faster
             const int code = p->tile / 1000000;        // 6/7: timing-only ablations; 8: the 4-wave block (A/B); 4x: tpb override (scripts/plane_gemm_probe.py)
             if (code >= 40 && code < 50) a.tpb = code - 40 + 1;
             int rc = ssdhip_gemm_planes_dma(p->x, p->w, p->y, a.M, p->Cin, p->Cout, p->rows_per_img, p->w_img_stride, BM, BN, a.tpb,

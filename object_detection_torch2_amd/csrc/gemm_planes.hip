@@ -39,7 +39,7 @@ struct PlaneWaves { static constexpr int value = (BM + BN == 256) ? 2 : 3; };
 
 // NW = 4: 2 x 2 waves of (BM/2) x (BN/2); NW = 8: 2 x 4 waves of (BM/2) x (BN/4) on the same block tile (twice the waves per SIMD for the
 // same LDS footprint: more latency cover for the barrier and the DMA stream, 1.25x the LDS fragment reads)
-template <int BM, int BN, int ABL = 0, int NW = 4>
+template <int BM, int BN, int ABL = 0, int NW = 4, int KTF = 0>      // KTF: K-steps per tile when known at compile time (K = 128: 4), else 0
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, PlaneWaves<BM, BN>::value * NW / 4))) void gemm_planes_dma_kernel(PlaneArgs a) {
     constexpr int WNC = NW / 2;                                    // waves along n
     constexpr int RPP = 8 * NW;                                    // operand rows one DMA pass of the block covers
@@ -49,6 +49,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, Plan
     float* Bs = lds + 2 * BM * LROW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WNC, wn = wave % WNC;
+    const int KT = KTF ? KTF : a.KT;
 
     int t;
     {
@@ -83,13 +84,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, Plan
         for (int i = 0; i < BL; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(ub + (b_off + (unsigned)(RPP * i) * rowK + kb)),
                                              (lptr_t)(b_dst + (buf * BN + RPP * i) * LROW), 16, 0, 0);
-        if (++ld_kt == a.KT) {
+        if (++ld_kt == KT) {
             if (ld_tile + 1 < ntl) {
                 ld_kt = 0; ++ld_tile;
                 a_off += (unsigned)BM * rowK;
                 ub = reinterpret_cast<const char*>(a.u) + (size_t)((m0 + ld_tile * BM) / a.rows_per_plane) * (size_t)a.u_plane_stride * 4;
             } else {
-                ld_kt = a.KT - 1;           // past the end: keep re-fetching the last step (never consumed)
+                ld_kt = KT - 1;           // past the end: keep re-fetching the last step (never consumed)
             }
         }
     };
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, Plan
     for (int kc = 0; kc < 4; ++kc) fko[kc] = (unsigned)(((2 * kc + fh) ^ fx) * 16);
     const unsigned a_lds = (unsigned)(uintptr_t)(lptr_t)(As + (wm * WROWS + frow) * LROW);
     const unsigned b_lds = (unsigned)(uintptr_t)(lptr_t)(Bs + (wn * WCOLS + frow) * LROW);
-    const int total = ntl * a.KT;
+    const int total = ntl * KT;
     int kt_in = 0, m_cur = m0;
     for (int g = 0; g < total; ++g) {
         const int buf = g & 1;
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, Plan
                     }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (++kt_in == a.KT) {             // tile finished: dense rows of M, then restart the accumulators
+        if (++kt_in == KT) {             // tile finished: dense rows of M, then restart the accumulators
             kt_in = 0;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
@@ -192,6 +193,7 @@ int ssdhip_gemm_planes_dma(const float* v, const float* u, float* y, int M, int 
     if (abl == 4) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128, 0, 4>), grid, block, 0, st, a);      // A/B: the 4-wave block
     else if (abl == 1) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128, 1>), grid, block, 0, st, a);
     else if (abl == 2) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128, 2>), grid, block, 0, st, a);
+    else if (BM == 128 && BN == 128 && K == 128) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128, 0, 8, 4>), grid, dim3(512), 0, st, a);   // short K: 4 steps, known at compile time
     else if (BM == 128 && BN == 128) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128, 0, 8>), grid, dim3(512), 0, st, a);   // 8 waves: +3 % (scripts/plane_gemm_probe.py)
     else if (BM == 128 && BN == 64) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 64>), grid, block, 0, st, a);
     else if (BM == 64 && BN == 128) hipLaunchKernelGGL((gemm_planes_dma_kernel<64, 128>), grid, block, 0, st, a);
