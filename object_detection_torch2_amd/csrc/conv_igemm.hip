@@ -531,7 +531,7 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
             const int code = p->tile / 1000000;        // 6/7: timing-only ablations; 8: the 4-wave block (A/B); 4x: tpb override (scripts/plane_gemm_probe.py)
             if (code >= 40 && code < 50) a.tpb = code - 40 + 1;
             int rc = ssdhip_gemm_planes_dma(p->x, p->w, p->y, a.M, p->Cin, p->Cout, p->rows_per_img, p->w_img_stride, BM, BN, a.tpb,
-                                            (hipStream_t)stream, code == 7 ? 1 : code == 6 ? 2 : code == 8 ? 4 : 0);
+                                            (hipStream_t)stream, code == 7 ? 1 : code == 6 ? 2 : code == 8 ? 4 : code == 3 ? 3 : 0);
             if (rc != SSDHIP_OK) { ssdhip_set_error("conv2d: plane GEMM tile not compiled"); return rc; }
             SSDHIP_CHECK_LAUNCH();
             return SSDHIP_OK;

@@ -144,9 +144,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, Plan
             } else if constexpr (MT == 2) {
                 if (kc < 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa[cur][0]), "+v"(fa[cur][1]), "+v"(fb[cur][0]));
                 else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[cur][0]), "+v"(fa[cur][1]), "+v"(fb[cur][0]));
-            } else {
+            } else if constexpr (NT == 2) {
                 if (kc < 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa[cur][0]), "+v"(fb[cur][0]), "+v"(fb[cur][1]));
                 else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[cur][0]), "+v"(fb[cur][0]), "+v"(fb[cur][1]));
+            } else {
+                if (kc < 3) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[cur][0]), "+v"(fb[cur][0]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[cur][0]), "+v"(fb[cur][0]));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -196,7 +199,8 @@ int ssdhip_gemm_planes_dma(const float* v, const float* u, float* y, int M, int 
     else if (BM == 128 && BN == 128 && K == 128) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128, 0, 8, 4>), grid, dim3(512), 0, st, a);   // short K: 4 steps, known at compile time
     else if (BM == 128 && BN == 128) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128, 0, 8>), grid, dim3(512), 0, st, a);   // 8 waves: +3 % (scripts/plane_gemm_probe.py)
     else if (BM == 128 && BN == 64) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 64>), grid, block, 0, st, a);
-    else if (BM == 64 && BN == 128) hipLaunchKernelGGL((gemm_planes_dma_kernel<64, 128>), grid, block, 0, st, a);
+    else if (BM == 64 && BN == 128 && abl == 3) hipLaunchKernelGGL((gemm_planes_dma_kernel<64, 128>), grid, block, 0, st, a);        // A/B: 4 waves
+    else if (BM == 64 && BN == 128) hipLaunchKernelGGL((gemm_planes_dma_kernel<64, 128, 0, 8>), grid, dim3(512), 0, st, a);       // 2 x 4 waves of 32 x 32
     else return SSDHIP_ENOSUP;
     return SSDHIP_OK;
 }

@@ -244,7 +244,7 @@ class Engine:
                                   # (gemm_planes.hip: BM, BN, ablation, waves, compile-time K-steps), other K on the register-staged one
                                   kernel=('gemm_planes_dma_kernel<128, 128, 0, 8, 4>' if (spec.cin == 128 and p.tile == 128128) else
                                           'gemm_planes_dma_kernel<128, 128, 0, 8, 0>' if (spec.cin >= 256 and p.tile == 128128) else
-                                          'gemm_planes_dma_kernel<%d, 128, 0, 4, 0>' % (p.tile // 1000) if spec.cin >= 256 else
+                                          'gemm_planes_dma_kernel<%d, 128, 0, 8, 0>' % (p.tile // 1000) if spec.cin >= 256 else
                                           'conv_igemm_kernel<%d, 128, 1, 0, false, false, 0, false>' % (p.tile // 1000)),
                                   direct_flops=2.0 * N * h * w * spec.cin * spec.cout * 9,
                                   flops=2.0 * 16 * tp * spec.cin * spec.cout, e0=e0, e1=e1))

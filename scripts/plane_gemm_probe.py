@@ -20,13 +20,13 @@ for name, Tp, cin, cout in SHAPES:
         p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout = 16, 1, Tp, cin, 1, Tp, cout
         p.R, p.S, p.stride, p.pad, p.KP, p.mode, p.accumulate, p.tile = 1, 1, 1, 0, cin, 0, 0, tile
         p.rows_per_img, p.w_img_stride = Tp, rows_pad * cin
-        ps[tile] = p
-        assert run(p, st) == 0, tile
+        if run(p, st) == 0:
+            ps[tile] = p
     torch.cuda.synchronize()
-    best = {t: 1e9 for t in codes}
+    best = {t: 1e9 for t in ps}
     for _ in range(6):                      # interleaved rounds: no first-measured bias
-        for t in codes:
+        for t in ps:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); run(ps[t], st); e1.record(); torch.cuda.synchronize(); best[t] = min(best[t], e0.elapsed_time(e1))
     fl = 2.0 * 16 * Tp * cin * cout
-    print(f'{name:9s} ' + ' '.join(f'{t}:{best[t]*1e3:.0f}us/{fl/best[t]/1e9:.0f}TF' for t in codes), flush=True)
+    print(f'{name:9s} ' + ' '.join(f'{t}:{best[t]*1e3:.0f}us/{fl/best[t]/1e9:.0f}TF' for t in ps), flush=True)
