@@ -222,6 +222,8 @@ def main():
         value = world * B * args.steps / dt
         metric = 'images/sec SSD300 train step, batch 32/GPU' if args.mode == 'train' else \
             'images/sec SSD300 inference (forward + decode + score + NMS), batch 32/GPU'
+        if B != 32 and args.imsize == 300:
+            metric = metric.replace('batch 32/GPU', f'batch {B}/GPU (not the BASELINE batch of 32)')
         line = dict(metric=metric, value=round(value, 2), unit='images/sec', n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
                     scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',

@@ -93,6 +93,7 @@ class Engine:
         self.dist_hook = None  # callable(flat_grad) for data-parallel all-reduce (parallel.py)
         self._side = {}        # device -> side stream (heads / weight gradients)
         self.single_stream = os.environ.get('SSD_SINGLE_STREAM', '0') == '1'
+        self._plane_limit = 1 << 30      # elements one plane-GEMM launch may address (tests lower it to exercise the grouping)
         self._readers = {}     # backbone stage -> events after which its output / BN state may be overwritten by the next
                                # backbone pass: the forward consumers (det_4_3 head, conv_6_1) and their weight gradients
         self.bf16 = False      # set per forward from module.compute_dtype; backward follows the saved forward
@@ -215,6 +216,22 @@ class Engine:
             spec.wino_key = key
         return spec.wino_u
 
+    def _plane_gemm(self, p, tp, cin, cout, w_plane_stride, what):
+        """ssdhip_conv2d_nhwc as 16 plane GEMMs; the kernel addresses its input with 32-bit byte offsets (2^30 elements), so big batches
+        run the planes in 2, 4 or 8 groups (same kernel, pointers advanced)."""
+        groups = 1
+        while (16 // groups) * tp * max(cin, cout) >= self._plane_limit and groups < 16:
+            groups *= 2
+        per = 16 // groups
+        x0, w0, y0 = p.x, p.w, p.y
+        p.N = per
+        for gi in range(groups):
+            p.x = x0 + gi * per * tp * cin * 4
+            p.w = w0 + gi * per * w_plane_stride * 4
+            p.y = y0 + gi * per * tp * cout * 4
+            _lib.check(self.lib.ssdhip_conv2d_nhwc(ctypes.byref(p), _lib.stream()), what)
+        p.x, p.w, p.y, p.N = x0, w0, y0, 16
+
     def _conv_winograd(self, spec, x, xs, z, ws, N, h, w, stats):
         """3x3/s1/p1 conv as input transform -> 16 plane GEMMs (one launch of the implicit-GEMM kernel) -> output transform.
         Returns the number of BN partial rows written to `stats`."""
@@ -233,11 +250,11 @@ class Engine:
         p.tile = 128128 if (16 * tp // 128) * ((spec.cout + 127) // 128) > 2000 else 64128
         p.rows_per_img, p.w_img_stride = tp, spec.rows_pad * spec.cin
         if self.prof is None:
-            _lib.check(L.ssdhip_conv2d_nhwc(ctypes.byref(p), st), f'winograd gemm {spec.name}')
+            self._plane_gemm(p, tp, spec.cin, spec.cout, spec.rows_pad * spec.cin, f'winograd gemm {spec.name}')
         else:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            _lib.check(L.ssdhip_conv2d_nhwc(ctypes.byref(p), st), f'winograd gemm {spec.name}')
+            self._plane_gemm(p, tp, spec.cin, spec.cout, spec.rows_pad * spec.cin, f'winograd gemm {spec.name}')
             e1.record()
             self.prof.append(dict(layer=spec.name + ' (winograd-domain GEMM)',
                                   # the symbol rocprofv3 shows: K >= 256 planes and the K = 128 specialisation run on the LDS-DMA kernel
@@ -267,7 +284,7 @@ class Engine:
         p.R, p.S, p.stride, p.pad, p.KP, p.mode, p.accumulate = 1, 1, 1, 0, spec.cin, 0, 0
         p.tile = 128128 if cp <= 128 else 128064
         p.rows_per_img, p.w_img_stride = tp, _rup(cp, 128) * spec.cin
-        _lib.check(L.ssdhip_conv2d_nhwc(ctypes.byref(p), st), f'winograd gemm {spec.name}')
+        self._plane_gemm(p, tp, spec.cin, cp, _rup(cp, 128) * spec.cin, f'winograd gemm {spec.name}')
         _lib.check(L.ssdhip_winograd_output_head(_lib.ptr(Mo), _lib.ptr(bias), out_ptr, out_batch_stride, N, h, w, spec.cout, cp, st),
                    f'winograd_output_head {spec.name}')
 
@@ -608,7 +625,7 @@ class Engine:
         if spec.cin < 128:
             p.tile = 128064
         p.rows_per_img, p.w_img_stride = tp, rows * spec.cout
-        _lib.check(L.ssdhip_conv2d_nhwc(ctypes.byref(p), st), f'winograd gemm (dgrad {spec.name})')
+        self._plane_gemm(p, tp, spec.cout, spec.cin, rows * spec.cout, f'winograd gemm (dgrad {spec.name})')
         _lib.check(L.ssdhip_winograd_output(_lib.ptr(Mo), None, _lib.ptr(dx), None, N, h, w, spec.cin, st), f'winograd_output (dgrad {spec.name})')
 
     def _dgrad(self, spec, dy, dx, N, hdy, wdy, hin, win, accumulate):

@@ -352,3 +352,21 @@ def test_odd_input_sizes_forward_and_backward(env, N, S):
     assert np.abs(out.detach().cpu().numpy() - ref.numpy()).max() < 3e-3
     out.sum().backward()
     assert all(torch.isfinite(p.grad).all() for p in net.train_params())
+
+
+def test_plane_gemm_grouping_for_large_batches(env):
+    """Batches beyond ~90 images exceed the 32-bit offset range of one 16-plane GEMM launch; the engine then runs the planes in
+    groups.  Lowering the limit exercises 2-, 4-, 8- and 16-group launches at a small batch: bit-identical outputs and gradients."""
+    synth = env['synth']
+    x = torch.from_numpy(synth.images(720, 2)).to(DEV)
+    ref = None
+    for limit in (1 << 30, 1 << 22, 1 << 20, 1 << 10):
+        net = make_net(env)
+        net._engine()._plane_limit = limit
+        out = net(x)
+        out.square().mean().backward()
+        got = (out.detach().clone(), net.detectors['det_7_1'].weight.grad.clone(), net.features['conv_6_1'].weight.grad.clone())
+        if ref is None:
+            ref = got
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(ref, got)), limit
