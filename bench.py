@@ -3,7 +3,11 @@
 batch 32 per GPU, fp32, synthetic 300x300x3 batches (BASELINE.json metric; workload = configs[2], at N>1 the weak-
 scaled data-parallel form with an RCCL gradient all-reduce).
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU.  Either torch.distributed.run starts the ranks (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+environment), or -- when WORLD_SIZE is not set -- this process starts N fresh child processes itself before it touches the
+GPU (never by replacing itself), waits for them and exits non-zero if any of them failed.
 
 Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around the launches of the dominant kernel
 inside the timed region; `cpu_baseline` times the CPU oracle (a port of the reference path) on a bounded sample.
@@ -16,9 +20,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 GFLOP_PER_IMAGE_TRAIN = 72.238     # fwd 62.747 + wgrad 7.114 + dgrad 2.376 (VGG frozen)
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
@@ -36,24 +37,59 @@ def host_cores():
     return min(n, 16) if n > 64 else n      # unrestricted many-core host: use the documented 16-core share of one GPU
 
 
-def cpu_baseline(batch=8, steps=2):
-    """The oracle's train step (stock torch CPU ops + numpy loss) on this host: a bounded sample of the same workload."""
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(batch=32, warmup=3, steps=5, budget_s=120.0):
+    """the oracle (a port of the reference path on stock torch CPU ops + numpy) on this host's cores, batch 32,
+    fp32, 3 warm-up + 5 timed iterations of the train step (zero_grad + forward + loss + backward + Adam) and of the inference
+    step (forward + decode + score + NMS on void-biased logits).  Bounded: each leg stops warming up / timing early when its
+    share of `budget_s` is spent (slow hosts), and says in `sample` how many iterations it really ran."""
+    import torch
     from oracle import ssd_oracle as O
     from object_detection_torch2_amd import synth
     cores = host_cores()
     torch.set_num_threads(cores)
     sd = O.init_state(seed=1)
     df = O.default_bboxes()
-    ims = torch.from_numpy(synth.images(7, batch))
-    tg = synth.targets(8, batch, g_max=8)
+    ims = torch.from_numpy(synth.images(100, batch))
+    tg = synth.targets(200, batch, g_max=8)
+
+    def timed(fn, budget):
+        t_start = time.perf_counter()
+        w = 0
+        while w < warmup and (w == 0 or time.perf_counter() - t_start < 0.3 * budget):
+            fn(); w += 1
+        t0 = time.perf_counter()
+        k = 0
+        while k < steps and (k == 0 or time.perf_counter() - t_start < budget):
+            fn(); k += 1
+        return w, k, time.perf_counter() - t0
+
     st = {}
-    O.train_step(sd, st, ims, tg, df)                 # warm-up
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        O.train_step(sd, st, ims, tg, df)
-    dt = time.perf_counter() - t0
-    return dict(value=round(batch * steps / dt, 3), unit='images/sec', cores=cores, kind='port',
-                sample=f'{steps} train steps at batch {batch} (1 warm-up), torch {torch.__version__} CPU ops, {cores} threads')
+    wt, kt, dt_t = timed(lambda: O.train_step(sd, st, ims, tg, df), budget_s * 0.55)
+
+    def infer():
+        with torch.no_grad():
+            out = O.forward(sd, ims, training=True).numpy()        # the reference never calls eval() (Q3)
+        out[:, :, 4] += 3.0                                        # SURVEY 8(d): void-biased logits, ~1.3 k NMS candidates per image
+        out[:, :, :4] = O.calc_coordicate(out, df)
+        out[:, :, 4:] = O.calc_score(out)
+        O.non_maximum_suppression(out)
+
+    wi, ki, dt_i = timed(infer, budget_s * 0.45)
+    return dict(value=round(batch * kt / dt_t, 3), unit='images/sec', cores=cores, kind='port',
+                inference_value=round(batch * ki / dt_i, 3), cpu=cpu_model(),
+                sample=f'train step: {wt} warm-up + {kt} timed at batch {batch}; inference step (forward + decode + score + NMS, '
+                       f'~1.3k candidates/image): {wi} warm-up + {ki} timed at batch {batch}; fp32, torch {torch.__version__} CPU ops, '
+                       f'{cores} threads; BASELINE.md §3 asks 3 + 5, fewer only where the {budget_s:.0f} s budget ran out')
 
 
 def step_gflop(eng, imsize):
@@ -75,6 +111,85 @@ def step_gflop(eng, imsize):
     return fwd / 1e9, (fwd + wgrad + dgrad) / 1e9
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment) from this process, which has not touched the GPU and never does; relay rank 0's stdout (the
+    one JSON line), send the other ranks' stdout to stderr; the first failing rank ends the job with its exit code."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()))
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL peer mappings fail without it on this driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, host_cores() // n)))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    live = list(procs)
+    while live and rc == 0:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is not None:
+                live.remove(p)
+                if code != 0:
+                    rc = code if code > 0 else 128 - code
+                    print(f'bench.py: rank {procs.index(p)} exited with code {code}; stopping the other ranks', file=sys.stderr)
+    for p in live:                       # a rank failed: its peers would wait in a collective forever
+        p.terminate()
+    for p in live:
+        try:
+            p.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    return rc
+
+
+def dry_run(args):
+    """Plumbing rehearsal without a GPU (tests/test_dist_cpu.py): rendezvous, the bench's barrier / max-over-ranks timing and the
+    bucketed all-reduce of a gradient-sized flat buffer over gloo -- no kernels, so its JSON line is labelled and is no measurement."""
+    import torch
+    import torch.distributed as dist
+    from object_detection_torch2_amd import parallel
+    rank, world, _ = parallel.init_from_env(backend='gloo')
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if os.environ.get('SSD_BENCH_TEST_FAIL_RANK') == str(rank):
+        raise SystemExit(7)
+    hook = parallel.GradAllReduce(n_buckets=2)
+    flat = torch.full((1 << 16,), float(rank + 1))
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        flat.fill_(float(rank + 1))
+        hook.start(flat, 1 << 15, flat.numel())
+        hook.finish(flat)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    ok = bool((flat == world * (world + 1) / 2).all())
+    if rank == 0:
+        print(json.dumps(dict(metric='DRY RUN (no GPU work): launcher + collective plumbing only', value=None, n_gpus=world, ranks=world,
+                              steps=args.steps, ms_per_step=round(dt / max(1, args.steps) * 1e3, 3), allreduce_ok=ok, dry_run=True)), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -92,8 +207,16 @@ def main():
                     help='extension (SURVEY 8(f)-4): un-freeze VGG16-bn (187.9 GFLOP/img instead of 72.2); never the headline')
     ap.add_argument('--mode', choices=['train', 'infer'], default='train',
                     help='train (headline, BASELINE configs[2]) or infer (configs[1]: forward + decode + score + NMS)')
+    ap.add_argument('--dry-run', action='store_true', help='no GPU: rehearse the launcher, rendezvous and all-reduce over gloo (CPU tests)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
+    if args.dry_run:
+        return dry_run(args)
+
+    import numpy as np  # noqa: F401
+    import torch
     from object_detection_torch2_amd import parallel, synth
     from object_detection_torch2_amd.model import SSD
     from object_detection_torch2_amd.optim import FusedAdam
@@ -110,6 +233,8 @@ def main():
     if args.finetune_backbone:
         net.finetune_backbone()
     net.set_compute_dtype(args.dtype)
+    if world > 1:
+        parallel.broadcast_module(net)      # replicas start from rank 0's weights whatever each process's RNG state was
     df = net.default_bboxes.to(dev)
     world_n = parallel.attach(net) if world > 1 else 1
     opt = FusedAdam(net.train_params(), lr=1e-3, weight_decay=5e-4, grad_scale=1.0 / world_n, on_step=net.hip_weights_changed)
@@ -217,6 +342,40 @@ def main():
         roof['note'] = '; '.join(notes) if notes else None
     eng.prof = None
 
+    comm = None
+    if world > 1 and args.mode == 'train':
+        # (a) the step's collective alone: the same bucket pattern on a scratch buffer of the gradient's size, nothing else running;
+        # (b) what the step pays for it: the same steps with the hook detached (weights diverge across ranks -- after the measurement)
+        hook, flat = eng.dist_hook, eng._flat['buf']
+        scratch = torch.zeros_like(flat)
+        cut = eng.grad_cut()
+        reps = 10
+        for _ in range(2):
+            hook.start(scratch, cut, scratch.numel()); hook.finish(scratch)
+        dist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            hook.start(scratch, cut, scratch.numel()); hook.finish(scratch)
+        e1.record()
+        torch.cuda.synchronize()
+        alone_ms = e0.elapsed_time(e1) / reps
+        eng.dist_hook = None
+        k = max(1, min(args.steps, 10))
+        step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(k):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t = torch.tensor([(time.perf_counter() - t1) / k * 1e3, alone_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        eng.dist_hook = hook
+        comm = dict(alone_ms=round(t[1].item(), 3), step_ms_without=round(t[0].item(), 3), bytes=flat.numel() * 4)
+
     gf_train, gf_fwd = GFLOP_PER_IMAGE_TRAIN, 62.747
     if args.imsize != 300 or args.finetune_backbone:
         gf_fwd, gf_train = step_gflop(eng, args.imsize)
@@ -235,7 +394,16 @@ def main():
                                 bn='train-mode batch statistics (reference never calls eval())', backbone='frozen VGG16-bn'),
                     conv_flop_roofline_frac=round(value / world * (gf_train if args.mode == 'train' else gf_fwd)
                                                   / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
-                    mean_loss=round(final_loss, 4))
+                    mean_loss=round(final_loss, 4), ranks=(dist.get_world_size() if world > 1 else 1))
+        if comm is not None:
+            # comm_ms_per_step: the gradient all-reduce of one step by itself (HIP events, max over ranks); the step hides most of
+            # it behind the last weight gradients and the next step's backbone -- comm_exposed_ms_per_step is what is left
+            line['comm_ms_per_step'] = comm['alone_ms']
+            line['comm_exposed_ms_per_step'] = round(dt / args.steps * 1e3 - comm['step_ms_without'], 3)
+            line['comm'] = dict(collective='all-reduce(sum) of the flat fp32 gradient buffer, 2 + 1 buckets', bytes=comm['bytes'],
+                                backend=dist.get_backend(), ms_per_step_without_allreduce=comm['step_ms_without'])
+        else:
+            line['comm_ms_per_step'] = 0.0
         if roof is not None:
             line['roofline'] = roof
         if args.imsize != 300:      # extension variant, never the headline: say so in every field a reader may look at

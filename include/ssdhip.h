@@ -72,7 +72,7 @@ typedef struct {
     int32_t KP;             /* packed row length (multiple of 32)                                */
     int32_t mode;           /* 0 fwd gather, 1 dgrad gather (x = dy, roles of Hi/Ho swapped by caller) */
     int32_t accumulate;     /* 1: y += result (second dgrad contribution)                        */
-    int32_t tile;           /* 0 auto, else BM*1000+BN (128128, 128064, 064128, 064064)          */
+    int32_t tile;           /* 0 auto, else BM*1000+BN (128128, 128064, 064128, 064064); nothing else */
     int32_t rows_per_img;   /* 0, or batched-GEMM use: output rows per weight plane (multiple of 128) */
     int64_t w_img_stride;   /* floats between consecutive weight planes (with rows_per_img)      */
     int32_t compute;        /* 0: exact fp32 MFMA (default, the headline path); 1: operands rounded to bf16 at LDS staging,
@@ -120,7 +120,9 @@ int ssdhip_bn_relu_pool(const float* x, const float* scale, const float* shift, 
  * outputs (N,P,4+C), targets (N,G,4+C) zero-padded rows, default boxes (P,4).
  * terms (3,N,P): l_loc, l_conf_pos, l_conf_neg;  cnt (N) int32 scratch;  sel (N,8) fp32:
  *   [thr_pos, thr_neg, pos_k, neg_k, inv_pos, per_image_loss, 0, 0];  loss (1).
- * Matching is bit-exact w.r.t. the reference's fp32 op order (no FMA contraction, IEEE divide).             */
+ * Matching is bit-exact w.r.t. the reference's fp32 op order (no FMA contraction, IEEE divide).
+ * C = number of classes incl. void, 2 <= C <= 1024 (ssd.py:9 is parametric; VOC's C = 21 has a register-resident
+ * specialisation, every other C runs the same arithmetic in the same order from memory).                     */
 int ssdhip_multibox_loss_fwd(const float* outputs, const float* targets, const float* dboxes,
                              int N, int P, int G, int C, float alpha, float threshold,
                              float* terms, int32_t* cnt, float* sel, float* loss, void* stream);

@@ -11,6 +11,10 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libssdhip.so')
+if os.environ.get('SSDHIP_PROBES') == '1':
+    # measurement scripts only (scripts/*_probe.py, *_bench.py): the probe build of the same sources (`make -C csrc probes`), which
+    # also holds the A/B and timing-only ablation kernels the product library refuses (tile codes >= 1,000,000)
+    LIB_PATH = os.path.join(_HERE, 'lib', 'libssdhip_probes.so')
 
 OK, EINVAL, ELAUNCH, ENOSUP = 0, -1, -2, -3
 

@@ -324,6 +324,125 @@ __global__ __launch_bounds__(256) void multibox_bwd_kernel(const float* __restri
     for (int c = 0; c < NC; ++c) go[4 + c] = gc[c] * coef;
 }
 
+// ---- any number of classes (SSD(num_classes) is parametric in the reference: ssd.py:9,70-77) --------------------------------
+// Same arithmetic, in the same order, as the C = 21 instantiations above (so the two agree bit for bit at C = 21); the per-class
+// values are recomputed from the logits instead of being held in registers, because the register arrays need a compile-time size.
+struct RowLsm {                  // log_softmax of one row, evaluated per class: (x[c] - max) - log(sum(exp(x - max)))
+    const float* x; float mx, ls;
+    __device__ __forceinline__ RowLsm(const float* row, int nc) : x(row) {
+        mx = row[0];
+        for (int c = 0; c < nc; ++c) mx = fmaxf(mx, row[c]);
+        float s = 0.0f;
+        for (int c = 0; c < nc; ++c) s += expf(row[c] - mx);
+        ls = logf(s);
+    }
+    __device__ __forceinline__ float at(int c) const { return (x[c] - mx) - ls; }
+};
+
+__global__ __launch_bounds__(256) void multibox_terms_rt_kernel(const float* __restrict__ outputs, const float* __restrict__ targets,
+                                                                const float* __restrict__ dboxes, int P, int G, int NC, float alpha,
+                                                                float threshold, float* __restrict__ terms, int* __restrict__ cnt, int N) {
+    extern __shared__ float gt[];  // (G, 4+NC)
+    const int ROW = 4 + NC;
+    const int n = blockIdx.y;
+    for (int i = threadIdx.x; i < G * ROW; i += blockDim.x) gt[i] = targets[(size_t)n * G * ROW + i];
+    __syncthreads();
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    bool any = false;
+    if (p < P) {
+        const float4 d = reinterpret_cast<const float4*>(dboxes)[p];
+        const float* row = outputs + ((size_t)n * P + p) * ROW;
+        float o0 = row[0], o1 = row[1], o2 = row[2], o3 = row[3];
+        const RowLsm lsm(row + 4, NC);
+        float l_loc = 0.0f, l_pos = 0.0f;
+        for (int g = 0; g < G; ++g) {
+            const float* t = gt + g * ROW;
+            float g_cx = t[0], g_cy = t[1], g_w = t[2], g_h = t[3];
+            if (!match_one(g_cx, g_cy, g_w, g_h, d.x, d.y, d.z, d.w, threshold)) continue;
+            any = true;
+            float h0 = (g_cx - d.x) / d.z;
+            float h1 = (g_cy - d.y) / d.w;
+            float h2 = g_w > 0.0f ? logf(g_w / d.z) : g_w;
+            float h3 = g_h > 0.0f ? logf(g_h / d.w) : g_h;
+            float s4 = ((smooth_l1(o0 - h0) + smooth_l1(o1 - h1)) + smooth_l1(o2 - h2)) + smooth_l1(o3 - h3);
+            l_loc += s4;
+            float ce = 0.0f;
+            for (int c = 0; c < NC; ++c) ce += t[4 + c] * lsm.at(c);
+            l_pos += -ce;
+        }
+        float l_neg = any ? 0.0f : -lsm.at(0);
+        size_t np = (size_t)N * P;
+        size_t idx = (size_t)n * P + p;
+        terms[idx] = l_loc;
+        terms[np + idx] = l_pos;
+        terms[2 * np + idx] = l_neg;
+    }
+    unsigned long long b = __ballot(any);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&cnt[n], (int)__popcll(b));
+}
+
+__global__ __launch_bounds__(256) void multibox_bwd_rt_kernel(const float* __restrict__ outputs, const float* __restrict__ targets,
+                                                              const float* __restrict__ dboxes, int N, int P, int G, int NC, float alpha,
+                                                              float threshold, const float* __restrict__ terms,
+                                                              const float* __restrict__ sel, const float* __restrict__ grad_out,
+                                                              float* __restrict__ grad) {
+    extern __shared__ float gt[];   // (G, 4+NC) rows, then G class-sums
+    const int ROW = 4 + NC;
+    float* tsum = gt + G * ROW;
+    const int n = blockIdx.y;
+    for (int i = threadIdx.x; i < G * ROW; i += blockDim.x) gt[i] = targets[(size_t)n * G * ROW + i];
+    __syncthreads();
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        float v = 0.0f;
+        for (int c = 0; c < NC; ++c) v += gt[g * ROW + 4 + c];
+        tsum[g] = v;
+    }
+    __syncthreads();
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const size_t np = (size_t)N * P, idx = (size_t)n * P + p;
+    const float* s = sel + (size_t)n * 8;
+    const float coef = s[4] * grad_out[0] / (float)N;
+    const bool pos_valid = terms[np + idx] > s[0];
+    const bool neg_valid = terms[2 * np + idx] > s[1];
+    const float4 d = reinterpret_cast<const float4*>(dboxes)[p];
+    const float* row = outputs + idx * ROW;
+    float o0 = row[0], o1 = row[1], o2 = row[2], o3 = row[3];
+    const RowLsm lsm(row + 4, NC);
+    float gl0 = 0.f, gl1 = 0.f, gl2 = 0.f, gl3 = 0.f;
+    bool any = false;
+    for (int g = 0; g < G; ++g) {
+        const float* t = gt + g * ROW;
+        float g_cx = t[0], g_cy = t[1], g_w = t[2], g_h = t[3];
+        if (!match_one(g_cx, g_cy, g_w, g_h, d.x, d.y, d.z, d.w, threshold)) continue;
+        any = true;
+        if (!pos_valid) continue;
+        float h0 = (g_cx - d.x) / d.z;
+        float h1 = (g_cy - d.y) / d.w;
+        float h2 = g_w > 0.0f ? logf(g_w / d.z) : g_w;
+        float h3 = g_h > 0.0f ? logf(g_h / d.w) : g_h;
+        gl0 += smooth_l1_grad(o0 - h0);
+        gl1 += smooth_l1_grad(o1 - h1);
+        gl2 += smooth_l1_grad(o2 - h2);
+        gl3 += smooth_l1_grad(o3 - h3);
+    }
+    float* go = grad + idx * ROW;
+    const float ca = coef * alpha;
+    go[0] = gl0 * ca; go[1] = gl1 * ca; go[2] = gl2 * ca; go[3] = gl3 * ca;
+    for (int c = 0; c < NC; ++c) {
+        const float smc = expf(lsm.at(c));
+        float gc = 0.0f;
+        if (any && pos_valid) {
+            for (int g = 0; g < G; ++g) {
+                const float* t = gt + g * ROW;
+                if (match_one(t[0], t[1], t[2], t[3], d.x, d.y, d.z, d.w, threshold)) gc += smc * tsum[g] - t[4 + c];
+            }
+        }
+        if (!any && neg_valid) gc += smc - (c == 0 ? 1.0f : 0.0f);
+        go[4 + c] = gc * coef;
+    }
+}
+
 __global__ void match_mask_kernel(const float* __restrict__ targets, const float* __restrict__ dboxes, int P, int G, int row,
                                   float threshold, uint8_t* __restrict__ mask) {
     const int n = blockIdx.y;
@@ -363,21 +482,26 @@ int ssdhip_multibox_loss_fwd(const float* outputs, const float* targets, const f
                              float alpha, float threshold, float* terms, int32_t* cnt, float* sel, float* loss, void* stream) {
     SSDHIP_REQUIRE(outputs && targets && dboxes && terms && cnt && sel && loss, "multibox_loss_fwd: null pointer");
     SSDHIP_REQUIRE(N > 0 && P > 0 && P <= 32768 && G >= 0, "multibox_loss_fwd: need 0 < P <= 32768");
-    SSDHIP_REQUIRE(C == 21, "multibox_loss_fwd: built for C = 21 (20 VOC classes + void)");
+    SSDHIP_REQUIRE(C >= 2 && C <= 1024, "multibox_loss_fwd: 2 <= C <= 1024 (void + at least one class)");
+    SSDHIP_REQUIRE(N <= 65535, "multibox_loss_fwd: N <= 65535");
     SSDHIP_REQUIRE((size_t)G * (4 + C) * 4 <= 64 * 1024, "multibox_loss_fwd: G too large for LDS staging");
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(cnt, 0, sizeof(int32_t) * N, st) != hipSuccess) { ssdhip_set_error("memset failed"); return SSDHIP_ELAUNCH; }
     size_t lds = (size_t)(G > 0 ? G : 1) * (4 + C) * sizeof(float);
-    hipLaunchKernelGGL(multibox_terms_kernel<21>, dim3(cdiv(P, 256), N), dim3(256), lds, st, outputs, targets, dboxes, P, G, alpha,
-                       threshold, terms, cnt, N);
+    if (C == 21)       // VOC (train.py:77): per-class values in registers
+        hipLaunchKernelGGL(multibox_terms_kernel<21>, dim3(cdiv(P, 256), N), dim3(256), lds, st, outputs, targets, dboxes, P, G, alpha,
+                           threshold, terms, cnt, N);
+    else
+        hipLaunchKernelGGL(multibox_terms_rt_kernel, dim3(cdiv(P, 256), N), dim3(256), lds, st, outputs, targets, dboxes, P, G, C, alpha,
+                           threshold, terms, cnt, N);
     SSDHIP_CHECK_LAUNCH();
     const int single = P > 16384;                       // two staged rows fit the 160 KiB LDS up to P = 16,384
     size_t lds2 = ((size_t)(single ? 1 : 2) * P + 258 + 2) * 4 + 16 * 8 + 8;
-    static bool lds_attr_set = false;
-    if (!lds_attr_set) {
+    static DeviceOnce lds_attr;                        // the attribute belongs to the kernel's per-device function object
+    if (const int dev = lds_attr.pending(); dev != DeviceOnce::kDone) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(multibox_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
             hipSuccess) { ssdhip_set_error("multibox_loss_fwd: cannot raise the dynamic LDS limit"); return SSDHIP_ELAUNCH; }
-        lds_attr_set = true;
+        lds_attr.mark(dev);
     }
     hipLaunchKernelGGL(multibox_select_kernel, dim3(N), dim3(1024), lds2, st, terms, cnt, N, P, alpha, sel, single);
     SSDHIP_CHECK_LAUNCH();
@@ -390,11 +514,15 @@ int ssdhip_multibox_loss_bwd(const float* outputs, const float* targets, const f
                              float alpha, float threshold, const float* terms, const float* sel, const float* grad_out,
                              float* grad, void* stream) {
     SSDHIP_REQUIRE(outputs && targets && dboxes && terms && sel && grad_out && grad, "multibox_loss_bwd: null pointer");
-    SSDHIP_REQUIRE(N > 0 && P > 0 && C == 21, "multibox_loss_bwd: built for C = 21");
+    SSDHIP_REQUIRE(N > 0 && N <= 65535 && P > 0 && C >= 2 && C <= 1024, "multibox_loss_bwd: need 0 < N <= 65535, P > 0, 2 <= C <= 1024");
     SSDHIP_REQUIRE((size_t)G * (4 + C) * 4 <= 64 * 1024, "multibox_loss_bwd: G too large for LDS staging");
     size_t lds = (size_t)(G > 0 ? G : 1) * (4 + C) * sizeof(float);
-    hipLaunchKernelGGL(multibox_bwd_kernel<21>, dim3(cdiv(P, 256), N), dim3(256), lds, (hipStream_t)stream, outputs, targets, dboxes,
-                       N, P, G, alpha, threshold, terms, sel, grad_out, grad);
+    if (C == 21)
+        hipLaunchKernelGGL(multibox_bwd_kernel<21>, dim3(cdiv(P, 256), N), dim3(256), lds, (hipStream_t)stream, outputs, targets, dboxes,
+                           N, P, G, alpha, threshold, terms, sel, grad_out, grad);
+    else
+        hipLaunchKernelGGL(multibox_bwd_rt_kernel, dim3(cdiv(P, 256), N), dim3(256), lds + (size_t)(G > 0 ? G : 1) * sizeof(float),
+                           (hipStream_t)stream, outputs, targets, dboxes, N, P, G, C, alpha, threshold, terms, sel, grad_out, grad);
     SSDHIP_CHECK_LAUNCH();
     return SSDHIP_OK;
 }

@@ -26,6 +26,19 @@ extern "C" void ssdhip_set_error(const char* msg);
         }                                                      \
     } while (0)
 
+// "Done once per device" flag for per-device driver state such as hipFuncSetAttribute (a kernel has one function object per
+// device, so a process-wide flag would leave every device but the first without its attribute).
+struct DeviceOnce {
+    static constexpr int kDone = -1, kUnknown = 64;
+    unsigned long long mask = 0;          // bit d: done on device ordinal d (benign race between threads: the action is idempotent)
+    int pending() const {                 // kDone, or the ordinal to hand to mark() once the action succeeded
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return kUnknown;
+        return ((__atomic_load_n(&mask, __ATOMIC_RELAXED) >> dev) & 1ull) ? kDone : dev;
+    }
+    void mark(int dev) { if (dev >= 0 && dev < 64) __atomic_fetch_or(&mask, 1ull << dev, __ATOMIC_RELAXED); }
+};
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -183,15 +183,15 @@ int ssdhip_conv_c64(const float* x, const float* wimg, const float* bias, const 
     SSDHIP_REQUIRE(Cout == 64 || Cout == 128 || Cout == 256, "conv_c64: Cout must be 64, 128 or 256");
     SSDHIP_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv_c64: in_scale and in_shift go together");
     SSDHIP_REQUIRE((int64_t)N * H * W * 64 < (1ll << 31), "conv_c64: tensor too large");
-    static bool attr_set = false;
+    static DeviceOnce attr;
     const size_t lds = (size_t)(W_IMAGE + 128) * sizeof(float);
-    if (!attr_set) {
+    if (const int dev = attr.pending(); dev != DeviceOnce::kDone) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             ssdhip_set_error("conv_c64: cannot enable 145 KiB dynamic LDS");
             return SSDHIP_ELAUNCH;
         }
-        attr_set = true;
+        attr.mark(dev);
     }
     const int groups = c64_groups(Cout);
     dim3 grid(groups * (Cout / 64)), block(C64_THREADS);

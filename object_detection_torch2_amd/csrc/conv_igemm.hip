@@ -501,9 +501,14 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
         SSDHIP_REQUIRE(p->Ho == (p->Hi + 2 * p->pad - p->R) / p->stride + 1 && p->Wo == (p->Wi + 2 * p->pad - p->S) / p->stride + 1,
                        "conv2d: output size does not match input/stride/pad");
     }
+#ifndef SSDHIP_PROBES
+    // tile codes >= 1,000,000 select A/B and timing-only ablation kernels (some return wrong results by design): they exist only in
+    // libssdhip_probes.so (make probes; used by scripts/*_probe.py, scripts/*_bench.py), never in the product library
+    SSDHIP_REQUIRE(p->tile >= 0 && p->tile < 1000000, "conv2d: tile must be 0 (auto) or one of 128128/128064/64128/64064");
+#endif
     SSDHIP_REQUIRE(p->compute == 0 || p->compute == 1, "conv2d: compute 0 (fp32 MFMA) or 1 (bf16 MFMA, fp32 accumulate)");
     const bool bf16 = p->compute == 1;
-    SSDHIP_REQUIRE(!bf16 || (p->Cin != 4 && p->rows_per_img == 0 && p->tile < 1000000), "conv2d: bf16 compute is for the plain conv layers");
+    SSDHIP_REQUIRE(!bf16 || (p->Cin != 4 && p->rows_per_img == 0), "conv2d: bf16 compute is for the plain conv layers");
     int BM, BN;
     SSDHIP_REQUIRE(choose_tile(p, BM, BN) == SSDHIP_OK, "conv2d: tile must be one of 128128/128064/64128/64064");
     SSDHIP_REQUIRE(p->rows_per_img == 0 || (p->rows_per_img % BM == 0 && p->mode == 0 && p->w_img_stride > 0),
@@ -527,11 +532,15 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
         if (a.tpb > 8) a.tpb = 8;
         // plain row-major planes: stage with the LDS-DMA engine (gemm_planes.hip) unless tile code 9xxxxxx asks for the
         // register-staged kernel (A/B comparison in scripts/wino_bench.py)
-        if (p->tile / 1000000 != 9 && !(BM == 64 && BN == 64) && p->KP == p->Cin && p->Cin % BK == 0 && (p->Cin >= 256 || (p->Cin == 128 && BM == 128 && BN == 128))) {   // other K = 128 tiles: register staging measured faster
-            const int code = p->tile / 1000000;        // 6/7: timing-only ablations; 8: the 4-wave block (A/B); 4x: tpb override (scripts/plane_gemm_probe.py)
-            if (code >= 40 && code < 50) a.tpb = code - 40 + 1;
+        int probe = 0;
+#ifdef SSDHIP_PROBES
+        const int code = p->tile / 1000000;        // 6/7: timing-only ablations; 8: the 4-wave block (A/B); 4x: tpb override (scripts/plane_gemm_probe.py)
+        if (code >= 40 && code < 50) a.tpb = code - 40 + 1;
+        probe = code == 7 ? 1 : code == 6 ? 2 : code == 8 ? 4 : code == 3 ? 3 : code == 9 ? 9 : 0;
+#endif
+        if (probe != 9 && !(BM == 64 && BN == 64) && p->KP == p->Cin && p->Cin % BK == 0 && (p->Cin >= 256 || (p->Cin == 128 && BM == 128 && BN == 128))) {   // other K = 128 tiles: register staging measured faster
             int rc = ssdhip_gemm_planes_dma(p->x, p->w, p->y, a.M, p->Cin, p->Cout, p->rows_per_img, p->w_img_stride, BM, BN, a.tpb,
-                                            (hipStream_t)stream, code == 7 ? 1 : code == 6 ? 2 : code == 8 ? 4 : code == 3 ? 3 : 0);
+                                            (hipStream_t)stream, probe);
             if (rc != SSDHIP_OK) { ssdhip_set_error("conv2d: plane GEMM tile not compiled"); return rc; }
             SSDHIP_CHECK_LAUNCH();
             return SSDHIP_OK;
@@ -540,6 +549,7 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
     a.OWf = p->Wo; a.oh0 = 0; a.ow0 = 0; a.ostep = 1; a.r0 = 0; a.s0 = 0; a.rstep = 1; a.nr = p->R; a.ns = p->S;
     hipStream_t st = (hipStream_t)stream;
     const bool xf = p->in_scale != nullptr;
+#ifdef SSDHIP_PROBES
     if (p->tile >= 1000000 && p->tile / 1000000 != 9) {   // timing-only ablations of the 128x128 3x3 kernel (scripts/conv_bench.py)
         SSDHIP_REQUIRE(BM == 128 && BN == 128 && p->R == 3 && p->mode == 0 && p->Cin != 4 && xf, "conv2d: ablation tile");
         dim3 grid(a.MB * a.NB), block(256);
@@ -548,6 +558,7 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
         SSDHIP_CHECK_LAUNCH();
         return SSDHIP_OK;
     }
+#endif
     const int key = BM * 1000 + BN;
 #define SSDHIP_CONV_CASE(bm, bn)                                            \
     case bm * 1000 + bn:                                                    \

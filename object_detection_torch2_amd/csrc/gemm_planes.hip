@@ -193,13 +193,17 @@ int ssdhip_gemm_planes_dma(const float* v, const float* u, float* y, int M, int 
     a.M = M; a.K = K; a.KT = K / BK; a.Cout = Cout; a.rows_per_plane = rows_per_plane;
     a.MB = M / BM; a.NB = cdiv(Cout, BN); a.tpb = tpb;
     dim3 grid(cdiv(a.MB, a.tpb) * a.NB), block(256);
-    if (abl == 4) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128, 0, 4>), grid, block, 0, st, a);      // A/B: the 4-wave block
-    else if (abl == 1) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128, 1>), grid, block, 0, st, a);
-    else if (abl == 2) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128, 2>), grid, block, 0, st, a);
-    else if (BM == 128 && BN == 128 && K == 128) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128, 0, 8, 4>), grid, dim3(512), 0, st, a);   // short K: 4 steps, known at compile time
+#ifdef SSDHIP_PROBES      // libssdhip_probes.so only: A/B variants and timing-only ablations (abl 1 / 2 return wrong results by design)
+    if (abl == 4) { hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128, 0, 4>), grid, block, 0, st, a); return SSDHIP_OK; }      // A/B: the 4-wave block
+    if (abl == 1) { hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128, 1>), grid, block, 0, st, a); return SSDHIP_OK; }
+    if (abl == 2) { hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128, 2>), grid, block, 0, st, a); return SSDHIP_OK; }
+    if (BM == 64 && BN == 128 && abl == 3) { hipLaunchKernelGGL((gemm_planes_dma_kernel<64, 128>), grid, block, 0, st, a); return SSDHIP_OK; }     // A/B: 4 waves
+#else
+    if (abl != 0) return SSDHIP_ENOSUP;
+#endif
+    if (BM == 128 && BN == 128 && K == 128) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128, 0, 8, 4>), grid, dim3(512), 0, st, a);   // short K: 4 steps, known at compile time
     else if (BM == 128 && BN == 128) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128, 0, 8>), grid, dim3(512), 0, st, a);   // 8 waves: +3 % (scripts/plane_gemm_probe.py)
     else if (BM == 128 && BN == 64) hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 64>), grid, block, 0, st, a);
-    else if (BM == 64 && BN == 128 && abl == 3) hipLaunchKernelGGL((gemm_planes_dma_kernel<64, 128>), grid, block, 0, st, a);        // A/B: 4 waves
     else if (BM == 64 && BN == 128) hipLaunchKernelGGL((gemm_planes_dma_kernel<64, 128, 0, 8>), grid, dim3(512), 0, st, a);       // 2 x 4 waves of 32 x 32
     else return SSDHIP_ENOSUP;
     return SSDHIP_OK;

@@ -64,6 +64,29 @@ __global__ __launch_bounds__(256) void decode_score_kernel(float* __restrict__ o
     for (int c = 0; c < NC; ++c) row[4 + c] = (c == arg) ? score : 0.0f;
 }
 
+// any number of classes: the same arithmetic as decode_score_kernel<NC> with the row read twice instead of held in registers
+__global__ __launch_bounds__(256) void decode_score_rt_kernel(float* __restrict__ outputs, const float* __restrict__ dboxes, int P, int NC,
+                                                              int64_t total) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int p = (int)(idx % P);
+    float* row = outputs + idx * (4 + NC);
+    float4 d = reinterpret_cast<const float4*>(dboxes)[p];
+    float cx = d.z * row[0] + d.x;
+    float cy = d.w * row[1] + d.y;
+    float w = d.z * expf(row[2]);
+    float h = d.w * expf(row[3]);
+    float mx = row[4];
+    int arg = 0;
+    for (int c = 1; c < NC; ++c)
+        if (row[4 + c] > mx) { mx = row[4 + c]; arg = c; }
+    float s = 0.0f;
+    for (int c = 0; c < NC; ++c) s += expf(row[4 + c] - mx);
+    float score = expf(row[4 + arg] - mx) / s;
+    row[0] = cx; row[1] = cy; row[2] = w; row[3] = h;
+    for (int c = 0; c < NC; ++c) row[4 + c] = (c == arg) ? score : 0.0f;
+}
+
 __global__ void calc_iou_kernel(const float* __restrict__ t, const float* __restrict__ s, int T, int S, int rowt, int rows,
                                 float* __restrict__ iou) {
     const int n = blockIdx.z;
@@ -558,9 +581,10 @@ extern "C" {
 
 int ssdhip_decode_score(float* outputs, const float* dboxes, int N, int P, int C, void* stream) {
     SSDHIP_REQUIRE(outputs && dboxes && N > 0 && P > 0, "decode_score: bad arguments");
-    SSDHIP_REQUIRE(C == 21, "decode_score: built for C = 21");
+    SSDHIP_REQUIRE(C >= 2 && C <= 1024, "decode_score: 2 <= C <= 1024");
     int64_t total = (int64_t)N * P;
-    hipLaunchKernelGGL(decode_score_kernel<21>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, outputs, dboxes, P, total);
+    if (C == 21) hipLaunchKernelGGL(decode_score_kernel<21>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, outputs, dboxes, P, total);
+    else hipLaunchKernelGGL(decode_score_rt_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, outputs, dboxes, P, C, total);
     SSDHIP_CHECK_LAUNCH();
     return SSDHIP_OK;
 }
@@ -582,8 +606,8 @@ static int nms_ws_impl(float* outputs, int N, int P, int C, float iou_thresh, ui
     SSDHIP_REQUIRE(outputs && ws_ptr && N > 0 && P > 0 && C >= 2, "nms_ws: bad arguments");
     SSDHIP_REQUIRE(P <= NMS_WS_MAX_P, "nms_ws: P <= 32768");
     SSDHIP_REQUIRE(N <= 65535, "nms_ws: N <= 65535");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr;
+    if (const int dev = attr.pending(); dev != DeviceOnce::kDone) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(nms_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 NMS_LDS_BYTES) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -593,7 +617,7 @@ static int nms_ws_impl(float* outputs, int N, int P, int C, float iou_thresh, ui
             ssdhip_set_error("nms_ws: cannot enable 128 KiB dynamic LDS");
             return SSDHIP_ELAUNCH;
         }
-        attr_set = true;
+        attr.mark(dev);
     }
     NmsWs ws;
     nms_ws_layout(N, P, &ws, reinterpret_cast<unsigned char*>(ws_ptr));
@@ -632,14 +656,14 @@ int ssdhip_nms(float* outputs, int N, int P, int C, float iou_thresh, uint8_t* k
     SSDHIP_REQUIRE(outputs && N > 0 && P > 0 && C >= 2, "nms: bad arguments");
     // LDS plan: idx16 (2P) + kept boxes (16P) + keep bits + misc must fit 160 KiB -> P <= 9000
     SSDHIP_REQUIRE(P <= 9000, "nms: P <= 9000 (all-LDS kept list); larger prior sets need the global-list variant");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr;
+    if (const int dev = attr.pending(); dev != DeviceOnce::kDone) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 NMS_LDS_BYTES) != hipSuccess) {
             ssdhip_set_error("nms: cannot enable 160 KiB dynamic LDS");
             return SSDHIP_ELAUNCH;
         }
-        attr_set = true;
+        attr.mark(dev);
     }
     int idx_bytes = ((2 * P + 15) / 16) * 16;
     int keepbits_bytes = (((P + 31) / 32 + 3) / 4 * 4) * 4;

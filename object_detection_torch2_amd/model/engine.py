@@ -517,6 +517,12 @@ class Engine:
             p += _rup(q.numel(), 4)
         return names, params, offs, p
 
+    def grad_cut(self):
+        """Offset in the flat gradient buffer behind the first tail stage's parameters: everything from here on is final before
+        that stage's weight gradient (the largest, last) runs, so the all-reduce of [cut, end) overlaps it."""
+        names, _, offs, _ = self.grad_layout()
+        return offs[names.index(f'features.{self.stages[self.tail_start + 1].conv.name}.weight')]
+
     def _flat_grad(self, dev):
         names, params, offs, total = self.grad_layout()
         if self._flat is None or self._flat['buf'].device != dev or self._flat['total'] != total:
@@ -702,9 +708,8 @@ class Engine:
             xin, xin_xs = (acts[i - 1][2], acts[i - 1][3]) if i > 0 else (b['x4'], None)
             if i == self.tail_start and self.dist_hook is not None:
                 # every gradient behind the first stage's parameters is final: reduce it while the largest wgrad runs
-                first = f'features.{c.name}.weight'
-                cut = self._flat['offs'][names.index(f'features.{self.stages[i + 1].conv.name}.weight')]
-                assert self._flat['offs'][names.index(first)] == 0
+                cut = self.grad_cut()
+                assert self._flat['offs'][names.index(f'features.{c.name}.weight')] == 0
                 fork.join()
                 self.dist_hook.start(flat, cut, flat.numel())
             with fork.side():

@@ -98,6 +98,7 @@ class SSD(nn.Module):
         self._ready_event = None
         self.compute_dtype = 'fp32'      # 'bf16': see set_compute_dtype
         self._engine_token = None
+        self._dist_hook = None           # parallel.attach: gradient all-reduce hook, handed to every engine this module builds
         self._default_bboxes = None      # generated lazily by the HIP kernel (first access needs the GPU)
 
         features = nn.ModuleDict()
@@ -191,6 +192,7 @@ class SSD(nn.Module):
     def _engine(self) -> Engine:
         if self._eng is None:
             self._eng = Engine(self)
+            self._eng.dist_hook = self._dist_hook      # survives a rebuilt launch plan (finetune_backbone after parallel.attach)
         return self._eng
 
     def hip_weights_changed(self):

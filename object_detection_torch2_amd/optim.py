@@ -17,36 +17,51 @@ class FusedAdam(torch.optim.Optimizer):
         self._on_step = on_step
         self._plans = {}
 
+    def invalidate(self):
+        """Forget the cached launch plans (device pointer table, device step counter): the next step() rebuilds them from
+        `self.state`.  Needed whenever state tensors are replaced behind the optimizer's back."""
+        self._plans = {}
+
+    def load_state_dict(self, state_dict):
+        """torch's loader replaces exp_avg / exp_avg_sq with new tensors and new step values: a plan cached before it would keep
+        writing into the old (freed) moment buffers and keep counting from the old step."""
+        super().load_state_dict(state_dict)
+        self.invalidate()
+
     def _plan(self, gi, group, params):
-        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in params)
+        for p in params:
+            st = self.state[p]
+            if 'exp_avg' not in st:
+                st['step'] = 0
+                st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]['exp_avg'].data_ptr(), self.state[p]['exp_avg_sq'].data_ptr())
+                    for p in params)
         plan = self._plans.get(gi)
         if plan is not None and plan['key'] == key:
             return plan
         dev = params[0].device
         rows, sizes, blocks = [], [], []
         for ti, p in enumerate(params):
-            if p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
-                raise ValueError('FusedAdam: contiguous fp32 parameters and gradients only')
             st = self.state[p]
-            if 'exp_avg' not in st:
-                st['step'] = 0
-                st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            for t in (p, p.grad, st['exp_avg'], st['exp_avg_sq']):
+                if t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
+                    raise ValueError('FusedAdam: contiguous fp32 parameters, gradients and moments on one device only')
             rows.append([p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr()])
             sizes.append(p.numel())
             blocks += [[ti, c] for c in range((p.numel() + _CHUNK - 1) // _CHUNK)]
         b1, b2 = group['betas']
-        old = plan
+        # the device step counter always restarts from the host-side per-parameter step (kept current by step(), replaced by
+        # load_state_dict), like torch.optim.Adam; one shared counter: the tensors of a group step together
+        step0 = int(max(int(self.state[p].get('step', 0)) for p in params))
         plan = dict(key=key, n_blocks=len(blocks),
                     table=torch.tensor(rows, dtype=torch.int64, device=dev),
                     sizes=torch.tensor(sizes, dtype=torch.int64, device=dev),
                     blockmap=torch.tensor(blocks, dtype=torch.int32, device=dev),
-                    hyper=old['hyper'] if old else torch.tensor([group['lr'], b1, b2, group['eps'], group['weight_decay'], 1.0, 1.0,
-                                                                 group['grad_scale']], dtype=torch.float32, device=dev),
-                    # device step counter; resumes from the checkpointed per-parameter step (load_state_dict), like torch.optim.Adam
-                    step=old['step'] if old else torch.full((1,), int(max(int(self.state[p].get('step', 0)) for p in params)),
-                                                            dtype=torch.int32, device=dev),
-                    host=old['host'] if old else (group['lr'], group['weight_decay'], group['grad_scale']))
+                    hyper=torch.tensor([group['lr'], b1, b2, group['eps'], group['weight_decay'], 1.0, 1.0, group['grad_scale']],
+                                       dtype=torch.float32, device=dev),
+                    step=torch.full((1,), step0, dtype=torch.int32, device=dev),
+                    host=(group['lr'], group['weight_decay'], group['grad_scale']))
         self._plans[gi] = plan
         return plan
 
@@ -73,6 +88,9 @@ class FusedAdam(torch.optim.Optimizer):
                                                     plan['n_blocks'], _CHUNK, _lib.ptr(plan['hyper']), st), 'adam')
             for p in params:
                 self.state[p]['step'] += 1
+            # the kernel wrote through raw pointers: tell torch (and every cache keyed on `_version`, e.g. the engine's packed and
+            # Winograd-domain weight images) that the parameters changed, with or without an on_step callback
+            torch.autograd.graph.increment_version(params)
         if self._on_step is not None:
             self._on_step()
         return loss

@@ -91,8 +91,62 @@ def attach(net, n_buckets=2, average=False, group=None):
     """Install the gradient all-reduce on an SSD module; returns the world size (use 1/world as FusedAdam grad_scale
     unless average=True)."""
     hook = GradAllReduce(group=group, n_buckets=n_buckets, average=average)
+    net._dist_hook = hook                # kept on the module: finetune_backbone() rebuilds the engine and must not drop it
     net._engine().dist_hook = hook
     return dist.get_world_size(group) if dist.is_initialized() else 1
+
+
+@torch.no_grad()
+def broadcast_module(net, src=0, group=None):
+    """Make every rank start from rank `src`'s model: parameters AND buffers (BatchNorm running statistics, step counters).
+    SSD() initialises with the process's own RNG state, which differs per process unless seeded, and the reference has no
+    notion of ranks; without this each replica would train a different model on averaged gradients.  One flat message per
+    dtype (a few large sends, as for the gradients)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    by_dtype = {}
+    for t in list(net.parameters()) + list(net.buffers()):
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for dtype, ts in by_dtype.items():
+        flat = torch.cat([t.detach().reshape(-1) for t in ts])
+        dist.broadcast(flat, src=src, group=group)
+        o = 0
+        for t in ts:
+            t.detach().copy_(flat[o:o + t.numel()].view_as(t))
+            o += t.numel()
+    if hasattr(net, 'hip_weights_changed'):
+        net.hip_weights_changed()            # raw copies above: packed / Winograd-domain weight images must be rebuilt
+
+
+@torch.no_grad()
+def broadcast_optimizer_state(opt, src=0, group=None):
+    """Same for a resumed optimizer: Adam moments and step counts of rank `src` (FusedAdam.state_dict layout = torch's)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for g in opt.param_groups:
+        for p in g['params']:
+            st = opt.state.get(p)
+            if not st:
+                continue
+            for k in ('exp_avg', 'exp_avg_sq'):
+                if k in st:
+                    dist.broadcast(st[k], src=src, group=group)
+            mine = st.get('step', 0)
+            step = torch.tensor([float(mine)], device=p.device)
+            dist.broadcast(step, src=src, group=group)
+            st['step'] = torch.tensor(step.item()) if torch.is_tensor(mine) else int(step.item())
+    if hasattr(opt, 'invalidate'):
+        opt.invalidate()
+
+
+def global_mean(value, device=None, group=None):
+    """Mean over ranks of a per-rank Python float (epoch loss): every rank gets the same number, so decisions taken from it
+    (checkpoint or not -> a collective inside) cannot diverge between ranks."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, group=group)
+    return t.item() / dist.get_world_size(group)
 
 
 @torch.no_grad()

@@ -25,6 +25,33 @@ from .model import SSD
 from .optim import FusedAdam
 
 
+def build_model(device, world, weights_path=None, weights_path_vgg16=None, num_classes=20 + 1, imsize=300):
+    """train.py:76-83 + the data-parallel start condition: every rank holds rank 0's parameters and buffers.  SSD() draws its
+    initial weights from the process's own (unseeded) RNG, so without the broadcast N ranks would train N different models."""
+    net = SSD(num_classes=num_classes, weights_path=weights_path, weights_path_vgg16=weights_path_vgg16, imsize=imsize)
+    net.to(device)
+    if world > 1:
+        parallel.broadcast_module(net)
+    return net
+
+
+def end_of_epoch(net, rank, world, epoch, local_loss, min_loss, lr, weights_path, params_path, device=None):
+    """train.py:141-152 under data parallelism.  `local_loss` is this rank's shard mean; the decision "improved?" is taken from
+    the mean over ranks, which every rank computes identically -- so the collective inside (averaging the BatchNorm running
+    statistics for the checkpoint) is entered by all ranks or by none.  Returns (global epoch loss, new min_loss)."""
+    loss = parallel.global_mean(local_loss, device=device) if world > 1 else float(local_loss)
+    if (min_loss is None) or (loss < min_loss):
+        if world > 1:
+            parallel.sync_bn_stats(net)
+        if rank == 0:
+            weights_path.parent.mkdir(parents=True, exist_ok=True)
+            torch.save(net.state_dict(), weights_path)
+            with open(params_path, 'w') as f:
+                json.dump({'min_loss': loss, 'lr': lr, 'last_epoch': epoch}, f, indent=4)
+        min_loss = loss
+    return loss, min_loss
+
+
 def main():
     parser = argparse.ArgumentParser()
     parser.add_argument('--purpose', type=str, default='detection')
@@ -52,9 +79,7 @@ def main():
     weights_path = Path(args.result_dir) / args.purpose / args.weights
     params_path = Path(args.result_dir) / args.purpose / args.params
 
-    net = SSD(num_classes=20 + 1, weights_path=weights_path,
-              weights_path_vgg16=Path(args.result_dir) / 'classification' / args.weights)
-    net.to(device)
+    net = build_model(device, world, weights_path, Path(args.result_dir) / 'classification' / args.weights)
     defaults = net.default_bboxes.to(device)
 
     if params_path.exists():
@@ -115,21 +140,14 @@ def main():
             loss.backward()
             optimizer.step()
             running += loss.detach()
-        running_loss = running.item() / max(n_steps, 1)
+        local_loss = running.item() / max(n_steps, 1)
         dt = time.perf_counter() - t0
+        # every rank: same global loss, same branch (the checkpoint branch holds a collective)
+        running_loss, min_loss = end_of_epoch(net, rank, world, epoch, local_loss, min_loss, scheduler.get_last_lr()[0],
+                                              weights_path, params_path, device=device)
         if rank == 0:
             print(f'[Epoch {epoch}/{args.epochs + start_epoch}] loss: {round(running_loss, 5)} lr: {scheduler.get_last_lr()[0]:.6f} '
                   f'({n_steps * args.batch_size * world / dt:.1f} img/s incl. data loading)')
-            if (min_loss is None) or (running_loss < min_loss):
-                parallel.sync_bn_stats(net) if world > 1 else None
-                weights_path.parent.mkdir(parents=True, exist_ok=True)
-                torch.save(net.state_dict(), weights_path)
-                min_loss = running_loss
-                with open(params_path, 'w') as f:
-                    json.dump({'min_loss': running_loss, 'lr': scheduler.get_last_lr()[0], 'last_epoch': epoch}, f, indent=4)
-        elif world > 1 and ((min_loss is None) or (running_loss < min_loss)):
-            parallel.sync_bn_stats(net)
-            min_loss = running_loss
         scheduler.step()
     if rank == 0:
         print('Finished Training')

@@ -48,7 +48,7 @@ def decode_score_(outputs: torch.Tensor, df: torch.Tensor) -> torch.Tensor:
 def calc_coordicate(pr: torch.Tensor, df: torch.Tensor) -> torch.Tensor:
     """utils.py:19-40: (N,P,>=4),(P,4) -> (N,P,4) decoded (cx,cy,w,h)."""
     if pr.shape[2] == 4:   # location-only input: give the fused kernel dummy class columns
-        pr = torch.cat([pr, pr.new_zeros(pr.shape[0], pr.shape[1], 21)], dim=2)
+        pr = torch.cat([pr, pr.new_zeros(pr.shape[0], pr.shape[1], 2)], dim=2)
     return _decode_score_copy(pr, df)[:, :, :4]
 
 

@@ -1,4 +1,5 @@
 """Per-layer timing of the HIP conv kernels at the SSD300 batch-32 shapes (forward; --bwd adds dgrad/wgrad of the tail)."""
+import os; os.environ.setdefault('SSDHIP_PROBES', '1')   # probe build of the library (make -C object_detection_torch2_amd/csrc probes)
 import sys, os, argparse
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

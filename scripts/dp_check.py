@@ -9,8 +9,12 @@ from object_detection_torch2_amd.model import SSD
 from object_detection_torch2_amd.optim import FusedAdam
 rank, world, local = parallel.init_from_env()
 dev = torch.device('cuda', local)
-torch.manual_seed(1)
-net = SSD(21).to(dev)
+from object_detection_torch2_amd import train
+net = train.build_model(dev, world)          # UNSEEDED on purpose: train.py's path must make the replicas equal (broadcast from rank 0)
+w0 = torch.cat([p.detach().reshape(-1) for p in net.parameters()] + [b.detach().reshape(-1).float() for b in net.buffers()])
+w0s = [torch.empty_like(w0) for _ in range(world)]
+dist.all_gather(w0s, w0)
+assert all(torch.equal(w0s[0], x) for x in w0s), 'replicas start from different weights'
 df = net.default_bboxes.to(dev)
 lo, hi = parallel.shard_batch(4 * world, rank, world)
 ims = torch.from_numpy(synth.images(5, 4 * world)[lo:hi]).to(dev)

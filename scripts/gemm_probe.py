@@ -1,4 +1,5 @@
 """How fast is the implicit-GEMM kernel as a plain 1x1 GEMM at Winograd-domain shapes (short K loops)?"""
+import os; os.environ.setdefault('SSDHIP_PROBES', '1')   # probe build of the library (make -C object_detection_torch2_amd/csrc probes)
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,5 +1,6 @@
 """Plane GEMM (gemm_planes.hip) at the Winograd-domain shapes of SSD300 batch 32: tile / tiles-per-block sweep and timing-only
 ablations (tile code 7 = no stores, 6 = no DMA after the first step, 5 = no barrier; results of 5/6/7 are wrong by design)."""
+import os; os.environ.setdefault('SSDHIP_PROBES', '1')   # probe build of the library (make -C object_detection_torch2_amd/csrc probes)
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,4 +1,5 @@
 """Winograd F(2x2,3x3) passes vs the direct implicit-GEMM kernel at the SSD300 batch-32 shapes."""
+import os; os.environ.setdefault('SSDHIP_PROBES', '1')   # probe build of the library (make -C object_detection_torch2_amd/csrc probes)
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

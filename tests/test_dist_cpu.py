@@ -75,3 +75,107 @@ def test_shard_batch_rejects_ragged():
     from object_detection_torch2_amd import parallel
     with pytest.raises(ValueError):
         parallel.shard_batch(65, 0, 2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bench.py --gpus N without a launcher: the parent starts the ranks itself (the driver's command line)
+# ---------------------------------------------------------------------------------------------------------------------
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(extra)
+    return env
+
+
+def test_bench_self_launches_two_ranks():
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--dry-run'],
+                       env=_bench_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout                      # ONE JSON line, from rank 0
+    assert lines[0]['ranks'] == 2 and lines[0]['n_gpus'] == 2 and lines[0]['allreduce_ok'] and lines[0]['dry_run']
+
+
+def test_bench_failing_rank_fails_the_job():
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--dry-run'],
+                       env=_bench_env(SSD_BENCH_TEST_FAIL_RANK='1'), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 7, (r.returncode, r.stderr[-2000:])
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{')]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# train.py under data parallelism: same start weights on every rank, rank-consistent checkpoint decision
+# ---------------------------------------------------------------------------------------------------------------------
+def _train_worker(rank, world, port, tmp, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import pathlib
+    from object_detection_torch2_amd import parallel, train
+    from object_detection_torch2_amd.model import SSD
+    parallel.init_from_env(backend='gloo')
+    torch.manual_seed(1234 + 77 * rank)              # what unseeded processes amount to: a different RNG state per rank
+    own = SSD(21)
+    own_sum = float(sum(p.double().sum() for p in own.parameters()))
+    torch.manual_seed(1234 + 77 * rank)
+    net = train.build_model(torch.device('cpu'), world)          # train.py's construction path
+    with torch.no_grad():
+        net.features['bn_7_1'].running_mean.fill_(float(rank + 1))
+    digest = torch.cat([p.detach().reshape(-1) for p in net.parameters()] + [b.detach().reshape(-1).float() for b in net.buffers()])
+    gathered = [torch.empty_like(digest) for _ in range(world)]
+    # buffers were set per rank AFTER the broadcast on purpose: compare parameters only here
+    n_par = sum(p.numel() for p in net.parameters())
+    dist.all_gather(gathered, digest)
+    same_start = all(torch.equal(gathered[0][:n_par], g[:n_par]) for g in gathered)
+    # epoch ends with rank-divergent shard losses: rank 0 keeps improving, rank 1 gets worse after epoch 1.  With per-rank
+    # decisions rank 1 would skip sync_bn_stats (a collective) in epochs 2 and 3 and rank 0 would hang in it.
+    wp, pp = pathlib.Path(tmp) / 'detection' / 'weights.pth', pathlib.Path(tmp) / 'detection' / 'params.json'
+    local = {0: [5.0, 4.0, 3.0, 9.0], 1: [5.0, 6.0, 6.5, 9.0]}[rank]
+    min_loss, hist = None, []
+    for epoch, l in enumerate(local, start=1):
+        g, min_loss = train.end_of_epoch(net, rank, world, epoch, l, min_loss, 1e-3, wp, pp)
+        hist.append((g, min_loss))
+    rm = float(net.features['bn_7_1'].running_mean[0])
+    q.put((rank, own_sum, same_start, hist, rm, wp.exists() if rank == 0 else None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_dp_same_start_and_rank_consistent_checkpoint_decision(tmp_path):
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] != res[1][1]                           # the two processes really drew different initial weights ...
+    assert res[0][2] and res[1][2]                          # ... and build_model made them equal (rank 0's)
+    assert res[0][3] == res[1][3]                           # same global loss and same min_loss on every rank, every epoch
+    assert [round(g, 6) for g, _ in res[0][3]] == [5.0, 5.0, 4.75, 9.0]
+    assert [m for _, m in res[0][3]] == [5.0, 5.0, 4.75, 4.75]     # improved in epochs 1 and 3 only
+    assert res[0][4] == res[1][4] == 1.5                    # BN running stats were averaged (collective ran on both ranks)
+    assert res[0][5]
+
+
+def test_attach_survives_finetune_backbone_in_both_orders():
+    from object_detection_torch2_amd import parallel
+    from object_detection_torch2_amd.model import SSD
+    a = SSD(21)
+    parallel.attach(a)
+    hook = a._engine().dist_hook
+    assert hook is not None
+    a.finetune_backbone()
+    assert a._engine().dist_hook is hook                    # the rebuilt engine got the same hook
+    b = SSD(21)
+    b.finetune_backbone()
+    parallel.attach(b)
+    assert b._engine().dist_hook is not None

@@ -61,6 +61,25 @@ def test_module_surface_matches_reference_contract():
     assert torch.equal(net.features['conv_6_1'].weight, ref['features.conv_6_1.weight'])
 
 
+def test_initialize_weights_statistics():
+    """A18 (ssd.py:135-158): extras + detectors kaiming_normal_(fan_out, relu) -> std = sqrt(2 / (Cout k^2)), conv bias 0,
+    BatchNorm gamma 1 / beta 0 (conv_6_1 std 0.01473 probed on the reference)."""
+    torch.manual_seed(0)
+    net = SSD(num_classes=21)
+    w = net.features['conv_6_1'].weight
+    assert abs(w.std().item() - 0.01473) < 2e-4 and abs(w.mean().item()) < 2e-5          # 4.7 M samples
+    for name, mod in list(net.features.items()) + list(net.detectors.items()):
+        if isinstance(mod, torch.nn.Conv2d):
+            cout, _, k, _ = mod.weight.shape
+            expect = (2.0 / (cout * k * k)) ** 0.5
+            n = mod.weight.numel()
+            assert abs(mod.weight.std().item() / expect - 1) < 4.0 / n ** 0.5 + 1e-3, name   # ~5 sigma of the std estimator
+            assert torch.count_nonzero(mod.bias).item() == 0, name
+        elif isinstance(mod, torch.nn.BatchNorm2d):
+            assert bool((mod.weight == 1).all()) and bool((mod.bias == 0).all()), name
+            assert bool((mod.running_mean == 0).all()) and bool((mod.running_var == 1).all()) and int(mod.num_batches_tracked) == 0
+
+
 def test_no_cpu_fallback():
     net = SSD(num_classes=21)
     with pytest.raises(RuntimeError, match='no CPU fallback'):
@@ -138,3 +157,39 @@ int main(void) {{
     subprocess.run(['gcc', '-std=c99', '-Wall', '-Werror', str(src), '-o', str(exe), f'-L{libdir}', '-lssdhip', f'-Wl,-rpath,{libdir}'], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split(maxsplit=2)
     assert int(out[0]) >= 100 and int(out[1]) < 0 and 'null pointer' in out[2]
+
+
+def test_product_library_refuses_probe_tile_codes():
+    """Tile codes >= 1,000,000 select A/B and timing-only ablation kernels (some return wrong results by design).  They are compiled
+    into libssdhip_probes.so only; the product library must reject them as invalid arguments (checked before any launch, so fake
+    device pointers are safe here)."""
+    import ctypes
+    lib = _lib.load()
+    p = _lib.ConvParams()
+    p.x, p.w, p.y = 0x1000, 0x2000, 0x3000
+    p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout = 16, 1, 128, 256, 1, 128, 256
+    p.R, p.S, p.stride, p.pad, p.KP, p.mode, p.accumulate, p.compute = 1, 1, 1, 0, 256, 0, 0, 0
+    p.y_batch_stride, p.rows_per_img, p.w_img_stride = 128 * 256, 128, 256 * 256
+    for code in (1128128, 6128128, 7128128, 8128128, 9128128, 41128128):
+        p.tile = code
+        assert lib.ssdhip_conv2d_nhwc(ctypes.byref(p), None) == _lib.EINVAL
+        assert b'tile' in lib.ssdhip_last_error()
+    import os
+    assert not os.path.exists(os.path.join(os.path.dirname(_lib.LIB_PATH), '..', '..', 'scripts', 'probes', 'mfma_shape_probe')) or True
+
+
+def test_product_library_refuses_probe_tile_codes():
+    """Tile codes >= 1,000,000 select A/B and timing-only ablation kernels (some return wrong results by design).  They are compiled
+    into libssdhip_probes.so only; the product library must reject them as invalid arguments (checked before any launch, so fake
+    device pointers are safe here)."""
+    import ctypes
+    lib = _lib.load()
+    p = _lib.ConvParams()
+    p.x, p.w, p.y = 0x1000, 0x2000, 0x3000
+    p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout = 16, 1, 128, 256, 1, 128, 256
+    p.R, p.S, p.stride, p.pad, p.KP, p.mode, p.accumulate, p.compute = 1, 1, 1, 0, 256, 0, 0, 0
+    p.y_batch_stride, p.rows_per_img, p.w_img_stride = 128 * 256, 128, 256 * 256
+    for code in (1128128, 6128128, 7128128, 8128128, 9128128, 41128128):
+        p.tile = code
+        assert lib.ssdhip_conv2d_nhwc(ctypes.byref(p), None) == _lib.EINVAL
+        assert b'tile' in lib.ssdhip_last_error()
