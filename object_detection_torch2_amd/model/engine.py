@@ -199,6 +199,15 @@ class Engine:
         self._bufs[key] = b
         return b
 
+    def _fused_ok(self, c, g, N):
+        """Layers that run on the fused Winograd kernel: 3x3/s1/p1, wide maps (>= 70 px: from the 38x38 maps down the three-pass form
+        is faster), channel counts the kernel tiles (Cin % 16, Cout % 64), tensors within its 32-bit offsets; fp32 mode only."""
+        if self.bf16 or c.is_head or os.environ.get('SSD_NO_FUSED_WINOGRAD') == '1':
+            return False
+        return (c.k == 3 and c.stride == 1 and c.pad == 1 and c.cin % 16 == 0 and c.cin <= 1024 and c.cout % 64 == 0
+                and min(g['hi'], g['wi']) >= 70 and N * g['hi'] * g['wi'] * max(c.cin * 4, c.cout) < (1 << 31)
+                and N * ((g['hi'] + 1) // 2) < 65536)
+
     @staticmethod
     def _wino_ok(g):
         return g['hi'] <= 160 and g['wi'] <= 160        # from the 150x150 maps down (x1.1 there, x1.8 at 38x38); 300x300 is transform-traffic-bound
@@ -432,7 +441,25 @@ class Engine:
                     for ev in self._readers.pop(i, ()):      # last step's readers of this stage's output / BN state
                         bb.wait_event(ev)
                 st = _lib.stream()
-                if c.wino and self._wino_ok(g) and not self.bf16:     # bf16 MFMA outruns the fp32 Winograd pipeline: direct kernel
+                if self._fused_ok(c, g, N):
+                    # conv_1_2 .. conv_3_3 (300x300 .. 75x75 maps): the one-kernel Winograd form (wino_fused.hip); nothing of the
+                    # Winograd domain in HBM.  Measured against the paths below (scripts/wf_bench.py, batch 32): conv_1_2 1.57 vs 1.80 ms,
+                    # conv_2_1 0.71 vs 0.86, conv_2_2 1.17 vs 1.6-1.9, conv_3_1 0.71 vs 0.79, conv_3_2/3 1.18 vs 1.23; from the 38x38
+                    # maps down the three-pass form wins (its 128x128 GEMM tiles need half the L2 -> LDS bytes per flop)
+                    w1, b1 = self._weight(c)
+                    key = (w1.data_ptr(), w1._version, self.m._hip_epoch if not c.frozen else 0)
+                    if getattr(c, 'wf_img', None) is None or c.wf_img.device != w1.device:
+                        c.wf_img = torch.empty(self.lib.ssdhip_wino_fused_weight_floats(c.cout, c.cin), device=w1.device, dtype=torch.float32)
+                        c.wf_key = None
+                    if c.wf_key != key:
+                        _lib.check(self.lib.ssdhip_wino_fused_pack(_lib.ptr(w1), _lib.ptr(c.wf_img), c.cout, c.cin, st), f'wino_fused_pack {c.name}')
+                        c.wf_key = key
+                    rows = _lib.check(self.lib.ssdhip_wino_fused_conv(_lib.ptr(cur), _lib.ptr(c.wf_img), _lib.ptr(b1) if b1 is not None else None,
+                                                                      _lib.ptr(cur_xs[0]) if cur_xs is not None else None,
+                                                                      _lib.ptr(cur_xs[1]) if cur_xs is not None else None, _lib.ptr(z),
+                                                                      _lib.ptr(ws['partial']) if training else None, N, g['hi'], g['wi'],
+                                                                      c.cin, c.cout, st), f'conv2d {c.name}')
+                elif c.wino and self._wino_ok(g) and not self.bf16:     # bf16 MFMA outruns the fp32 Winograd pipeline: direct kernel
                     rows = self._conv_winograd(c, cur, cur_xs, z, ws, N, g['hi'], g['wi'], ws['partial'] if training else None)
                 elif (c.cin == 64 and c.cout in (64, 128) and c.k == 3 and c.stride == 1 and c.pad == 1 and min(g['hi'], g['wi']) >= 100
                       and not self.bf16):

@@ -91,6 +91,40 @@ def conv_c64(x, w_oihw, bias=None, in_scale=None, in_shift=None, want_stats=Fals
     return z, stats
 
 
+def wino_fused_pack(w_oihw):
+    """OIHW (Cout % 64 == 0, Cin % 8 == 0, 3, 3) -> the fused Winograd kernel's weight image (one LDS-ready 32 KiB block per
+    64-channel tile and 8-channel K-step)."""
+    _lib.require_gpu(w_oihw)
+    lib = _lib.load()
+    w = _lib.f32c(w_oihw)
+    cout, cin = w.shape[0], w.shape[1]
+    if tuple(w.shape[2:]) != (3, 3):
+        raise ValueError(f'wino_fused_pack: 3x3 filters only, got {tuple(w.shape)}')
+    upk = torch.empty(_lib.check(lib.ssdhip_wino_fused_weight_floats(cout, cin), 'wino_fused_weight_floats'), device=w.device, dtype=torch.float32)
+    _lib.check(lib.ssdhip_wino_fused_pack(_lib.ptr(w), _lib.ptr(upk), cout, cin, _lib.stream()), 'wino_fused_pack')
+    return upk
+
+
+def wino_fused_conv(x, w_oihw, bias=None, in_scale=None, in_shift=None, want_stats=False, upk=None):
+    """3x3/s1/p1 conv as ONE fused Winograd F(2x2,3x3) kernel: x (N,H,W,Cin) NHWC -> (z (N,H,W,Cout), stats (MB,Cout,2) or None)."""
+    _lib.require_gpu(x, w_oihw)
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    cout, cin = w_oihw.shape[0], w_oihw.shape[1]
+    if cin != C:
+        raise ValueError(f'wino_fused_conv: input has {C} channels, weights expect {cin}')
+    if upk is None:
+        upk = wino_fused_pack(w_oihw)
+    z = torch.empty(N, H, W, cout, device=x.device, dtype=torch.float32)
+    stats = torch.empty(_lib.check(lib.ssdhip_wino_fused_stat_rows(N, H, W), 'wino_fused_stat_rows'), cout, 2, device=x.device,
+                        dtype=torch.float32) if want_stats else None
+    _lib.check(lib.ssdhip_wino_fused_conv(_lib.ptr(x), _lib.ptr(upk), _lib.ptr(bias) if bias is not None else None,
+                                          _lib.ptr(in_scale) if in_scale is not None else None,
+                                          _lib.ptr(in_shift) if in_shift is not None else None, _lib.ptr(z),
+                                          _lib.ptr(stats) if stats is not None else None, N, H, W, C, cout, _lib.stream()), 'wino_fused_conv')
+    return z, stats
+
+
 def conv2d_dgrad(dy, w_oihw, in_hw, stride=1, pad=0, accumulate_into=None, tile=0, bf16=False):
     """dy (N,Ho,Wo,Cout_pad) -> dx (N,Hi,Wi,Cin): data gradient of conv2d(x, w, stride, pad)."""
     _lib.require_gpu(dy, w_oihw)

@@ -246,6 +246,39 @@ def test_conv3x3_winograd(case):
     assert rel_err(z2.permute(0, 3, 1, 2).cpu(), ref2) < 1e-4
 
 
+# (N, H, W, Cin, Cout): odd / even maps, ragged last tile block (T % 64 != 0), one and several channel tiles, short and long K
+WINO_FUSED_CASES = [(2, 19, 19, 64, 64), (1, 38, 38, 64, 128), (3, 9, 11, 16, 64), (2, 30, 30, 128, 256), (1, 16, 12, 512, 192),
+                    (5, 11, 13, 48, 64), (1, 150, 150, 32, 64)]
+
+
+@pytest.mark.parametrize('case', WINO_FUSED_CASES)
+def test_conv3x3_winograd_fused(case):
+    """The one-kernel Winograd F(2x2,3x3) convolution (wino_fused.hip) vs F.conv2d: fused BN+ReLU of the input with zero padding
+    after it, bias, BatchNorm partial sums; then a plain input without bias (layer after a pool).  Same tolerance as the
+    three-pass form.  It must also agree with the three-pass form to rounding of the output transform (same products)."""
+    from object_detection_torch2_amd import ops
+    N, H, W, cin, cout = case
+    zprev = rnd(N, cin, H, W, seed=131)
+    scale, shift = rnd(cin, seed=132), rnd(cin, seed=133) + 0.5
+    w = rnd(cout, cin, 3, 3, seed=134, scale=(2.0 / (cin * 9)) ** 0.5)
+    b = rnd(cout, seed=135)
+    a = F.relu(zprev * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    ref = F.conv2d(a, w, b, padding=1)
+    x = ops.to_nhwc(zprev.to(DEV))
+    z, stats = ops.wino_fused_conv(x, w.to(DEV), b.to(DEV), in_scale=scale.to(DEV), in_shift=shift.to(DEV), want_stats=True)
+    got = z.permute(0, 3, 1, 2).cpu()
+    assert rel_err(got, ref) < 1e-4
+    s = stats.sum(dim=0).cpu()
+    assert torch.allclose(s[:, 0], ref.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(s[:, 1], (ref * ref).sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
+    ref2 = F.conv2d(zprev, w, None, padding=1)
+    z2, _ = ops.wino_fused_conv(x, w.to(DEV))
+    assert rel_err(z2.permute(0, 3, 1, 2).cpu(), ref2) < 1e-4
+    if cin % 32 == 0 and 256 % (cout // 4) == 0:
+        z3, _ = ops.conv3x3_winograd(x, w.to(DEV), b.to(DEV), in_scale=scale.to(DEV), in_shift=shift.to(DEV))
+        assert rel_err(z.cpu(), z3.cpu()) < 2e-6
+
+
 # (N, H, W, Cin, Cout): conv_6_1-like and detector-head-like (Cout padded 150 -> 160, 100 -> 128), odd / even maps
 WINO_WGRAD_CASES = [(2, 19, 19, 64, 128), (2, 10, 10, 128, 150), (3, 7, 9, 64, 100), (1, 38, 38, 64, 100)]
 

@@ -85,8 +85,45 @@ def test_gradients_vs_oracle_autograd(env):
         # the per-kernel tests (test_gpu_layers.py) carry the tight element-wise bound.
         rel = ((g - r).norm() / r.norm()).item()
         cos = (g * r).sum().item() / (g.norm().item() * r.norm().item())
-        tol = 1e-3 if k.startswith('detectors.') else 5e-2
+        tol = 1e-3 if k.startswith('detectors.') else 2.5e-2           # measured <= 1.1e-2; see test_gradients_no_worse_than_torch_fp32
         assert rel < tol and cos > 0.998, (k, rel, cos)
+
+
+def test_gradients_no_worse_than_torch_fp32(env):
+    """What the L2 tolerances above rest on, as a test: with ONE common dL/d outputs, every trainable gradient of the HIP path and of
+    torch's fp32 CPU path is compared with an fp64 run of the same network.  Both fp32 paths lose a few ReLU units that sit within
+    rounding of 0 (a different few each), which moves single weight gradients by percents; the HIP path must not be worse than
+    torch-fp32 by more than the spread between two such draws (measured ratio 0.03 .. 3.3 per tensor, median 1.0), and not worse
+    in aggregate."""
+    O, synth = env['O'], env['synth']
+    ims, tg, df = synth.images(40, 2), synth.targets(50, 2, g_max=8), O.default_bboxes()
+    names = [k for k in O.trainable_param_names() if not ('features.conv' in k and k.endswith('.bias'))]
+    sd32 = O.init_state(1)
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in O.init_state(1).items()}
+    for k in names:
+        sd32[k].requires_grad_(True); sd64[k].requires_grad_(True)
+    o32 = O.forward(sd32, torch.from_numpy(ims), training=True)
+    gout = torch.from_numpy(O.loss_grad(o32.detach().numpy(), tg, df))
+    o32.backward(gout)
+    o64 = O.forward(sd64, torch.from_numpy(ims).double(), training=True)
+    o64.backward(gout.double())
+    net = make_net(env)
+    out = net(torch.from_numpy(ims).to(DEV))
+    out.backward(gout.to(DEV))
+    e_out_hip = (out.detach().cpu().double() - o64.detach()).abs().max().item()
+    e_out_t32 = (o32.detach().double() - o64.detach()).abs().max().item()
+    assert e_out_hip < 4 * e_out_t32 + 1e-5, (e_out_hip, e_out_t32)            # measured 3.0e-4 vs 1.5e-4
+    got = dict(net.named_train_params())
+    tot_h = tot_t = 0.0
+    for k in names:
+        r = sd64[k].grad
+        n = r.norm().item()
+        eh = (got[k].grad.cpu().double() - r).norm().item() / n
+        et = (sd32[k].grad.double() - r).norm().item() / n
+        assert eh < 4 * et + 1e-6, (k, eh, et)
+        assert eh < 2e-2, (k, eh)                                               # measured <= 6.7e-3 (torch fp32: <= 1.1e-2)
+        tot_h += eh; tot_t += et
+    assert tot_h < 1.5 * tot_t, (tot_h, tot_t)
 
 
 def test_train_trajectory_vs_golden(env, golden):
@@ -110,11 +147,24 @@ def test_train_trajectory_vs_golden(env, golden):
     # step 0 is a pure forward+loss check; later steps go through backward + Adam (Adam amplifies rounding: 2e-3 rel)
     assert abs(losses[0] - fx['losses'][0]) < 2e-3
     assert np.allclose(losses, fx['losses'], rtol=2e-3), (losses, fx['losses'].tolist())
+    # Parameters after the 3 steps vs the reference's torch.optim.Adam.  Each step moves a parameter by <= lr = 1e-3, so a bound
+    # near 3e-3 would hold for ANY Adam; these bounds are 30x below that.  Adam divides by sqrt(v): an element whose gradient is
+    # of the size of its fp32 rounding error can take a step of opposite sign, which only happens in the conv weights behind ReLU
+    # units at rounding distance of 0 (test_gradients_no_worse_than_torch_fp32): for those the bulk is bounded, not the tail.
+    # Measured (scripts/tol_probe.py): det_4_3.weight 1.9e-5, bn_7_1.weight 2.8e-5, det_11_2.bias 3.0e-5, bn_11_2.bias 8.3e-5;
+    # conv weights median 5e-5 / 8.5e-5.  The reference-vs-oracle difference on the same tensors is 5e-6 .. 9e-6.
     sd = net.state_dict()
-    for k in ('detectors.det_4_3.weight', 'features.bn_7_1.weight', 'features.bn_11_2.bias'):
+    init = O.init_state(seed=1)
+    for k in [n[2:] for n in fx.files if n.startswith('p_')]:
         ref = fx['p_' + k]
         got = sd[k].cpu().numpy().reshape(-1)[::101]
-        assert np.abs(got - ref).max() < 3.1e-3, k                    # <= 3 Adam steps of lr 1e-3
+        moved = np.abs(ref - init[k].numpy().reshape(-1)[::101]).max()
+        assert moved > 2e-3, k                                         # the reference really moved these parameters
+        d = np.abs(got - ref)
+        if k.startswith('features.conv'):
+            assert np.median(d) < 2e-4 and np.quantile(d, 0.9) < 1e-3, (k, np.median(d), np.quantile(d, 0.9))
+        else:
+            assert d.max() < 1e-4, (k, d.max())
 
 
 def test_stock_torch_adam_also_works(env):
@@ -396,8 +446,52 @@ def test_headline_batch_vs_oracle(env):
             continue
         g, r = got[k].grad.cpu().double(), sd[k].grad.double()
         rel = ((g - r).norm() / r.norm()).item()
-        assert rel < (1e-3 if k.startswith('detectors.') else 5e-2), (k, rel)   # measured <= 1.1e-2 (ReLU units at rounding distance of 0)
+        assert rel < (1e-3 if k.startswith('detectors.') else 2.5e-2), (k, rel)   # measured <= 1.1e-2 (ReLU units at rounding distance of 0)
     stats = net.state_dict()
     for k in stats:
         if k.endswith('running_mean') or k.endswith('running_var'):
             assert torch.allclose(stats[k].cpu(), sd[k].detach(), rtol=2e-4, atol=2e-5), k
+
+
+def test_fused_adam_follows_replaced_state_and_bumps_versions(env):
+    """(a) Optimizer.load_state_dict replaces exp_avg / exp_avg_sq / step AFTER steps have run: the cached launch plan must not keep
+    the old moment buffers or the old step count.  (b) Without an on_step callback the engine must still see the new weights
+    (the raw-pointer update bumps each parameter's version counter)."""
+    import io
+    from object_detection_torch2_amd.optim import FusedAdam
+    synth = env['synth']
+    ims = torch.from_numpy(synth.images(90, 2)).to(DEV)
+    tgs = torch.from_numpy(synth.targets(91, 2)).to(DEV)
+
+    def run(net, opt, k):
+        out = []
+        for _ in range(k):
+            opt.zero_grad()
+            loss = net.loss(net(ims), tgs, df)
+            loss.backward()
+            opt.step()
+            out.append(loss.item())
+        return out
+
+    a, b, c = make_net(env), make_net(env), make_net(env)
+    df = a.default_bboxes.to(DEV)
+    oa = FusedAdam(a.train_params(), lr=1e-3, weight_decay=5e-4)                    # no on_step: version bump only
+    ob = FusedAdam(b.train_params(), lr=1e-3, weight_decay=5e-4, on_step=b.hip_weights_changed)
+    v0 = a.detectors['det_4_3'].weight._version
+    la, lb = run(a, oa, 3), run(b, ob, 3)
+    assert la == lb                                                                   # (b) stale packed weights would change step 2, 3
+    assert a.detectors['det_4_3'].weight._version > v0
+    # (a): c walks 2 steps, is checkpointed, walks 2 more (plan cached), then is rolled back to the checkpoint IN PLACE
+    oc = FusedAdam(c.train_params(), lr=1e-3, weight_decay=5e-4)
+    run(c, oc, 2)
+    buf = io.BytesIO()
+    torch.save({'net': c.state_dict(), 'opt': oc.state_dict()}, buf)
+    run(c, oc, 2)
+    buf.seek(0)
+    ck = torch.load(buf, map_location=DEV, weights_only=True)
+    c.load_state_dict(ck['net'])
+    oc.load_state_dict(ck['opt'])
+    third = run(c, oc, 1)[0]
+    assert third == la[2]                                                             # == the uninterrupted run's third step
+    for (k, x), (_, y) in zip(a.state_dict().items(), c.state_dict().items()):
+        assert torch.equal(x, y), k
