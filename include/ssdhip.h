@@ -218,15 +218,20 @@ int ssdhip_conv_c64(const float* x, const float* wimg, const float* bias, const 
 
 /* ---- A3 + A4 partials  the 3x3/s1/p1 layers of the backbone (model/vgg16.py:33: nn.Conv2d(cin, v, kernel_size=3, padding=1)) as ONE
  * fused Winograd F(2x2,3x3) kernel: input transform (with the producer's BN.ReLU), the 16 Winograd-domain products on the fp32
- * MFMA and the output transform + bias + BatchNorm partial sums, nothing of the Winograd domain in HBM.
- * x (N,H,W,Cin) NHWC, Cin % 8 == 0; upk = ssdhip_wino_fused_pack(w OIHW (Cout,Cin,3,3)), Cout % 64 == 0, of
- * ssdhip_wino_fused_weight_floats(Cout, Cin) floats; in_scale/in_shift (Cin) or both NULL; z (N,H,W,Cout);
- * stats NULL or (ssdhip_wino_fused_stat_rows(N,H,W), Cout, 2).  Returns the number of stats rows (>= 0) or a negative code.  */
+ * MFMA and the output transform + bias + BatchNorm partial sums, nothing of the Winograd domain in HBM.  Persistent grid (one
+ * block per CU) that walks (tile block, channel tile) items as one software pipeline.
+ * x (N,H,W,Cin) NHWC, Cin % 16 == 0, 32 <= Cin <= 512, W >= 9; upk = ssdhip_wino_fused_pack(w OIHW (Cout,Cin,3,3)), Cout % 64 == 0,
+ * of ssdhip_wino_fused_weight_floats(Cout, Cin) floats; in_scale/in_shift (Cin) or both NULL; z (N,H,W,Cout);
+ * stats NULL or (ssdhip_wino_fused_stat_rows(N,H,W), Cout, 2); geo = tile-block geometry of the map shape, filled once per
+ * (N,H,W) by ssdhip_wino_fused_geo into ssdhip_wino_fused_geo_bytes(N,H,W) bytes (caller-owned, reusable by every layer and
+ * step of that shape).  ssdhip_wino_fused_conv returns the number of stats rows (>= 0) or a negative code.                   */
 int64_t ssdhip_wino_fused_weight_floats(int Cout, int Cin);
 int ssdhip_wino_fused_pack(const float* w_oihw, float* upk, int Cout, int Cin, void* stream);
 int ssdhip_wino_fused_stat_rows(int N, int H, int W);
+int64_t ssdhip_wino_fused_geo_bytes(int N, int H, int W);
+int ssdhip_wino_fused_geo(int N, int H, int W, void* geo, void* stream);
 int ssdhip_wino_fused_conv(const float* x, const float* upk, const float* bias, const float* in_scale, const float* in_shift, float* z,
-                           float* stats, int N, int H, int W, int Cin, int Cout, void* stream);
+                           float* stats, const void* geo, int N, int H, int W, int Cin, int Cout, void* stream);
 
 /* ---- 8(f)-4  full fine-tuning (train.py:69-74 un-freezes nothing; extension): backward of MaxPool2d(2,2,pad) over the
  * recomputed a = relu(z*scale+shift) (vgg16.py:28-35): dpooled (N,Ho,Wo,C) -> da (N,H,W,C), gradient to the first maximum

@@ -15,7 +15,13 @@
 // transform is computed ONCE per block (each thread owns half a patch x 4 channels of one tile: 160 VALU instructions per
 // thread and K-step) and shared through LDS, rather than recomputed by every wave that needs it (256: 20 % slower).
 //
-//   block   256 threads = 4 waves as 2 (tiles) x 2 (channels): 64 consecutive tiles x 64 output channels x 16 planes
+//   grid    persistent: <= 256 blocks (one per CU), each walks its work items (tile block, channel tile) as ONE software pipeline:
+//           the DMAs and the input transform of the next item's first K-steps run under the current item's last MFMAs, so an
+//           item costs its K loop plus the output transform.  (One block per item paid 13 us of launch, geometry decode, two
+//           exposed DMA latencies and store drain per item -- 37 % of conv_1_2, whose K loop has only 8 steps.)
+//   item    256 threads = 4 waves as 2 (tiles) x 2 (channels): 64 consecutive tiles x 64 output channels x 16 planes
+//   geometry per tile block a 3.5 KiB record (pixel of every raw-tile slot, patch origin / masks / output pixel of every tile),
+//           computed once per (N, H, W) by wino_fused_geo_kernel and fetched by DMA one item ahead: no divisions in the pipeline
 //   K loop  8 input channels per step; per wave and step 16 planes x 4 MFMAs (4,096 MFMA cycles)
 //   x       the pixels under the block's 64 tiles (per tile-row segment a strip of 4 rows x (2 len + 2) pixels), the step's 8
 //           channels, by LDS-DMA into a raw tile (buffer_load ... lds; out-of-image pixels read 0 through the bounds check): every
@@ -39,6 +45,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -47,14 +54,17 @@ constexpr int WF_PLANE = 64 * WF_BK * 4;              // bytes of one plane of a
 constexpr int WF_OPER = 16 * WF_PLANE;                // 32 KiB: one operand image of one K-step
 constexpr int WF_SLOTS = 640;                         // pixel slots of the raw input tile (512 + 8 per tile-row segment, <= 16 segments)
 constexpr int WF_QUAD = WF_SLOTS * 16;                // bytes of one channel quad of the raw tile
-constexpr int WF_MAXC = 1024;
+constexpr int WF_MAXC = 512;
+constexpr int WF_REC_INTS = WF_SLOTS + 4 * WF_TILES;  // geometry record of one tile block: slot pixels, then one int4 per tile
+constexpr int WF_REC_BYTES = WF_REC_INTS * 4;         // 3,584
 constexpr int WF_A_OFF = 0;                           // 2 A images
 constexpr int WF_B_OFF = 2 * WF_OPER;                 // 2 B images
 constexpr int WF_RAW_OFF = 4 * WF_OPER;               // raw tile: the step's 2 channel quads of every slot
 constexpr int WF_SS_OFF = WF_RAW_OFF + 2 * WF_QUAD;   // scale[Cin], shift[Cin]
-constexpr int WF_TAB_OFF = WF_SS_OFF + 2 * WF_MAXC * 4;   // per-tile output table: 64 x int2
-constexpr int WF_RED_OFF = WF_TAB_OFF + 64 * 8;       // stats exchange: 2 (wm) x 64 (channel) x 2 floats
-constexpr int WF_LDS = WF_RED_OFF + 2 * 64 * 2 * 4;   // 161,280 B of the CU's 163,840
+constexpr int WF_REC_OFF = WF_SS_OFF + 2 * WF_MAXC * 4;   // geometry records of the current and the next item
+constexpr int WF_RED_OFF = WF_REC_OFF + 2 * WF_REC_BYTES; // stats exchange: 2 (wm) x 64 (channel) x 2 floats
+constexpr int WF_LDS = WF_RED_OFF + 2 * 64 * 2 * 4;   // 163,840 B: all of the CU's LDS
+static_assert(WF_LDS == 160 * 1024, "the LDS plan is meant to fill the CU exactly");
 
 struct WfArgs {
     const float* x;
@@ -62,14 +72,12 @@ struct WfArgs {
     const float* bias;
     const float* scale;
     const float* shift;
+    const int* geo;
     float* z;
     float* stats;
-    int H, W, C, Cout, TH, TW, T, KT, NB, RT;      // RT = N * TH tile rows
+    int H, W, C, Cout, KT, NB, MB;
     unsigned x_bytes;
-    unsigned magic_tw, magic_th;                  // ceil(2^32 / d): n / d == umulhi(n, magic) for n * d < 2^32
 };
-
-__device__ __forceinline__ int fdiv(int n, unsigned magic) { return (int)__umulhi((unsigned)n, magic); }
 
 // U[xi] = (G g G^T)[xi], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; same operation order as winograd_weight_kernel
 __device__ __forceinline__ float wino_u(const float* __restrict__ g9, int xi) {
@@ -97,122 +105,131 @@ __global__ void wino_fused_pack_kernel(const float* __restrict__ w, float* __res
     }
 }
 
-// Geometry of a block's 64 consecutive tiles t0 .. t0 + 63 (row-major over (n, th, tw)): segment 0 is the rest of tile row R0
-// from column tw0 (len0 tiles), segments 1.. are whole tile rows, the last one possibly cut short.  Segment k owns the pixel strip
-// rows 2 th - 1 .. 2 th + 2, columns 2 tws - 1 .. 2 (tws + len) of its image, 4 x (2 len + 2) slots starting at seg_off(k).
-struct WfGeo {
-    int R0, tw0, len0, off1, rowslots;
-    __device__ __forceinline__ int seg_len(int k, int TW) const { return k == 0 ? len0 : min(TW, WF_TILES - len0 - (k - 1) * TW); }
-    __device__ __forceinline__ int seg_off(int k) const { return k == 0 ? 0 : off1 + (k - 1) * rowslots; }
-};
+// Geometry of tile block mb = its 64 consecutive tiles t0 .. t0 + 63 (row-major over (n, th, tw)): segment 0 is the rest of tile
+// row R0 from column tw0 (len0 tiles), segments 1.. are whole tile rows, the last one possibly cut short.  Segment k owns the
+// pixel strip rows 2 th - 1 .. 2 th + 2, columns 2 tws - 1 .. 2 (tws + len) of its image: 4 x (2 len + 2) raw-tile slots.
+// Record: slot -> pixel index (n H + h) W + w or -1 (outside the image / unused); tile -> {slot of patch position (0, 0), slots per
+// patch row, masks (bits 0-3 patch rows inside the image, 4-7 patch columns, 8 tile exists, 9 / 10 second output row / column
+// exists), output pixel index (n H + 2 th) W + 2 tw}.  One block per tile block; depends on (N, H, W) only.
+__global__ __launch_bounds__(256) void wino_fused_geo_kernel(int* __restrict__ geo, int H, int W, int TH, int TW, int T, int RT) {
+    int* rec = geo + (size_t)blockIdx.x * WF_REC_INTS;
+    const int tid = threadIdx.x, t0 = blockIdx.x * WF_TILES;
+    const int R0 = t0 / TW, tw0 = t0 - R0 * TW, len0 = min(WF_TILES, TW - tw0);
+    const int off1 = 4 * (2 * len0 + 2), rowslots = 4 * (2 * TW + 2);
+    auto seg_len = [&](int k) { return k == 0 ? len0 : min(TW, WF_TILES - len0 - (k - 1) * TW); };
+    auto seg_off = [&](int k) { return k == 0 ? 0 : off1 + (k - 1) * rowslots; };
+    const int nseg = len0 == WF_TILES ? 1 : 1 + (WF_TILES - len0 + TW - 1) / TW;
+    const int total_slots = seg_off(nseg - 1) + 4 * (2 * seg_len(nseg - 1) + 2);
+    for (int s = tid; s < WF_SLOTS; s += 256) {
+        int pix = -1;
+        if (s < total_slots) {
+            const int k = s < off1 ? 0 : 1 + (s - off1) / rowslots;
+            const int rem = s - seg_off(k), width = 2 * seg_len(k) + 2;
+            const int r = rem / width, col = rem - r * width;
+            const int R = R0 + k, n = R / TH, th = R - n * TH;
+            const int h = 2 * th - 1 + r, w = 2 * (k == 0 ? tw0 : 0) - 1 + col;
+            if (R < RT && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) pix = (n * H + h) * W + w;
+        }
+        rec[s] = pix;
+    }
+    if (tid < WF_TILES) {
+        int ex = 0, ey = 0, ez = 0, ew = 0;
+        if (t0 + tid < T) {
+            int k = 0, c = tid;
+            if (tid >= len0) { const int ii = tid - len0; k = 1 + ii / TW; c = ii - (k - 1) * TW; }
+            const int R = R0 + k, tw = (k == 0 ? tw0 : 0) + c, n = R / TH, th = R - n * TH;
+            ex = seg_off(k) + 2 * c;
+            ey = 2 * seg_len(k) + 2;
+            ez = 1 << 8;
+            for (int r = 0; r < 4; ++r) if ((unsigned)(2 * th - 1 + r) < (unsigned)H) ez |= 1 << r;
+            for (int j = 0; j < 4; ++j) if ((unsigned)(2 * tw - 1 + j) < (unsigned)W) ez |= 16 << j;
+            if (2 * th + 1 < H) ez |= 1 << 9;
+            if (2 * tw + 1 < W) ez |= 1 << 10;
+            ew = (n * H + 2 * th) * W + 2 * tw;
+        }
+        int* t = rec + WF_SLOTS + 4 * tid;
+        t[0] = ex; t[1] = ey; t[2] = ez; t[3] = ew;
+    }
+}
 
 // ABL (probe builds only, wrong results by design): bit 0 = no raw-tile DMA in the K loop, bit 1 = no weight DMA in the K loop,
-// bit 2 = no activation / input transform in the K loop
+// bit 2 = no activation / input transform in the K loop, bit 3 = no output stores, bit 4 = one K-step per item
 template <bool XFORM, int ABL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_fused_kernel(WfArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int nb = blockIdx.x % a.NB, mb = blockIdx.x / a.NB;
-    const int t0 = mb * WF_TILES, n0 = nb * WF_COUT;
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)lds;
-    const int TW = a.TW, TH = a.TH;
+    // work items id = blockIdx.x + j * gridDim.x; the host makes gridDim.x a multiple of NB, so the channel tile is fixed per block
+    const int G = gridDim.x, items = a.MB * a.NB;
+    const int cnt = (items - (int)blockIdx.x + G - 1) / G;
+    const int nb = blockIdx.x % a.NB, mb0 = blockIdx.x / a.NB, mbstep = G / a.NB;
+    const int n0 = nb * WF_COUT;
+    const int KT = (ABL & 16) ? 4 : a.KT;
 
-    WfGeo geo;
-    geo.R0 = t0 / TW;                       // uniform: scalar division once per block
-    geo.tw0 = t0 - geo.R0 * TW;
-    geo.len0 = min(WF_TILES, TW - geo.tw0);
-    geo.off1 = 4 * (2 * geo.len0 + 2);
-    geo.rowslots = 4 * (2 * TW + 2);
-    const int nseg = geo.len0 == WF_TILES ? 1 : 1 + (WF_TILES - geo.len0 + TW - 1) / TW;
-    const int total_slots = geo.seg_off(nseg - 1) + 4 * (2 * geo.seg_len(nseg - 1, TW) + 2);
-
-    // ---- byte offset in x of every pixel slot (0x80000000 = outside the image / unused: the DMA then writes 0), via LDS:
-    // thread t decodes slots t, t + 256, t + 512; afterwards each lane keeps the slots of its 5 DMA pieces
-    {
-        unsigned* tab = reinterpret_cast<unsigned*>(lds + WF_A_OFF);          // the A images are idle until the prologue fills one
-        for (int s = tid; s < WF_SLOTS; s += 256) {
-            unsigned o = 0x80000000u;
-            if (s < total_slots) {
-                const int k = s < geo.off1 ? 0 : 1 + (s - geo.off1) / geo.rowslots;
-                const int rem = s - geo.seg_off(k);
-                const int width = 2 * geo.seg_len(k, TW) + 2;
-                const int r = rem / width, col = rem - r * width;
-                const int R = geo.R0 + k;
-                const int n = fdiv(R, a.magic_th), th = R - n * TH;
-                const int h = 2 * th - 1 + r, w = 2 * (k == 0 ? geo.tw0 : 0) - 1 + col;
-                if (R < a.RT && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W)
-                    o = (unsigned)(((n * a.H + h) * a.W + w) * a.C * 4);
-            }
-            tab[s] = o;
-        }
-        // BatchNorm scale / shift of the producer, once per block
-        if (XFORM) {
-            float* ss = reinterpret_cast<float*>(lds + WF_SS_OFF);
-            for (int c = tid; c < a.C; c += 256) { ss[c] = a.scale[c]; ss[WF_MAXC + c] = a.shift[c]; }
-        }
-        // output table: float offset of pixel (n, 2 th, 2 tw) of each tile and what exists of its 2x2 outputs
-        if (tid < 64) {
-            const int i = tid;
-            int2 ent = make_int2(0, 0);
-            if (t0 + i < a.T) {
-                int k = 0, c = i;
-                if (i >= geo.len0) { const int ii = i - geo.len0; const int q = fdiv(ii, a.magic_tw); k = 1 + q; c = ii - q * TW; }
-                const int R = geo.R0 + k, tw = (k == 0 ? geo.tw0 : 0) + c;
-                const int n = fdiv(R, a.magic_th), th = R - n * TH;
-                ent.x = ((n * a.H + 2 * th) * a.W + 2 * tw) * a.Cout;
-                ent.y = 1 | (2 * th + 1 < a.H ? 2 : 0) | (2 * tw + 1 < a.W ? 4 : 0);
-            }
-            *reinterpret_cast<int2*>(lds + WF_TAB_OFF + i * 8) = ent;
-        }
+    if (XFORM) {          // BatchNorm scale / shift of the producer, once per block
+        float* ss = reinterpret_cast<float*>(lds + WF_SS_OFF);
+        for (int c = tid; c < a.C; c += 256) { ss[c] = a.scale[c]; ss[WF_MAXC + c] = a.shift[c]; }
     }
-    __syncthreads();
-    // raw-tile DMA: 2 quads x 10 pieces of 64 slots; wave w moves pieces 5 w .. 5 w + 4 (waves 0, 1: quad 0; waves 2, 3: quad 1)
-    unsigned dof[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) dof[k] = reinterpret_cast<const unsigned*>(lds + WF_A_OFF)[64 * ((5 * wave + k) % 10) + lane];
-    __syncthreads();
 
-    // ---- staging role of this thread: tile = lane, hh = upper (patch rows 0-2 -> planes 0-7) / lower (rows 3-1 -> planes 8-15)
-    // half of the patch, q = which 4 of the step's 8 channels.  hh and q are wave-uniform.
+    // ---- per-item state: dof = byte offsets in x of this lane's 5 raw-tile DMA slots (2 quads x 10 pieces of 64 slots; wave w
+    // moves pieces 5 w .. 5 w + 4); staging role: tile = lane, hh = upper (patch rows 0-2 -> planes 0-7) / lower (rows 3-1 ->
+    // planes 8-15) half of the patch, q = which 4 of the step's 8 channels (hh, q wave-uniform); pb = LDS address of patch
+    // position (row r, column 0), hi = +inf where the position lies inside the image
     const int hh = wave & 1, q = wave >> 1;
-    unsigned pb[3];
+    unsigned dof[5], pb[3];
     float hi[3][4];
-    {
-        const int i = lane;
-        int k = 0, c = i;
-        if (i >= geo.len0) { const int ii = i - geo.len0; const int qq = fdiv(ii, a.magic_tw); k = 1 + qq; c = ii - qq * TW; }
-        const int width = 2 * geo.seg_len(k, TW) + 2;
-        const int R = geo.R0 + k, tw = (k == 0 ? geo.tw0 : 0) + c;
-        const int n = fdiv(R, a.magic_th), th = R - n * TH;
-        const bool tv = t0 + i < a.T;
+    int recN[5];
+    i32x4 tileN;            // the next item's record entries, read one step before they are adopted
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(a.geo), 0, (unsigned)a.MB * WF_REC_BYTES, 0x00020000);
+    const unsigned rec_vo = (unsigned)(wave * 1024 + lane * 16);
+    auto dma_rec = [&](int j, int slot) {   // geometry record of item j -> record buffer slot & 1 (3.5 KiB: the last wave moves half a piece)
+        if (rec_vo < (unsigned)WF_REC_BYTES)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (lptr_t)(lds + WF_REC_OFF + (slot & 1) * WF_REC_BYTES + wave * 1024), 16, rec_vo,
+                                                     (mb0 + j * mbstep) * WF_REC_BYTES, 0, 0);
+    };
+    auto read_slots = [&](int j) {     // 5 LDS reads (asm: see read_patch)
+        const unsigned rb = lds0 + (unsigned)(WF_REC_OFF + (j & 1) * WF_REC_BYTES);
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            asm volatile("ds_read_b32 %0, %1" : "=v"(recN[k]) : "v"(rb + (unsigned)((64 * ((5 * wave + k) % 10) + lane) * 4)));
+    };
+    auto read_tile = [&](int j) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(tileN) : "v"(lds0 + (unsigned)(WF_REC_OFF + (j & 1) * WF_REC_BYTES + WF_SLOTS * 4 + lane * 16)));
+    };
+#define WF_TIE_SLOTS() asm volatile("" : "+v"(recN[0]), "+v"(recN[1]), "+v"(recN[2]), "+v"(recN[3]), "+v"(recN[4]))
+#define WF_TIE_TILE() asm volatile("" : "+v"(tileN))
+    auto adopt_dof = [&]() {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) dof[k] = recN[k] < 0 ? 0x80000000u : (unsigned)(recN[k] * a.C * 4);    // beyond num_records: reads 0
+    };
+    auto adopt_tile = [&]() {
+        const bool tv = (tileN.z >> 8) & 1;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int pr = hh ? 3 - r : r;                       // upper half: patch rows 0, 1, 2; lower half: rows 3, 2, 1
-            pb[r] = lds0 + (unsigned)(WF_RAW_OFF + q * WF_QUAD + (tv ? (geo.seg_off(k) + pr * width + 2 * c) * 16 : 0));
-            const int h = 2 * th - 1 + pr;
+            pb[r] = lds0 + (unsigned)(WF_RAW_OFF + q * WF_QUAD + (tv ? (tileN.x + pr * tileN.y) * 16 : 0));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int w = 2 * tw - 1 + j;
-                hi[r][j] = (tv && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W) ? __builtin_inff() : 0.0f;
-            }
+            for (int j = 0; j < 4; ++j) hi[r][j] = (((tileN.z >> pr) & 1) && ((tileN.z >> (4 + j)) & 1)) ? __builtin_inff() : 0.0f;
         }
-    }
+    };
+
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
-    auto dma_raw = [&](int g) {        // the 8 channels of step g of every pixel slot -> raw tile (this wave's 5 pieces)
+    auto dma_raw = [&](int g) {        // the 8 channels of K-step g of every pixel slot -> raw tile (this wave's 5 pieces)
         const int quad = wave >> 1;
         char* d = lds + WF_RAW_OFF + quad * WF_QUAD + ((5 * wave) % 10) * 1024;
         const int soff = g * 32 + quad * 16;
 #pragma unroll
         for (int k = 0; k < 5; ++k) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lptr_t)(d + k * 1024), 16, dof[k], soff, 0, 0);
     };
-    const char* bsrc = reinterpret_cast<const char*>(a.upk) + (size_t)nb * a.KT * WF_OPER + wave * (WF_OPER / 4) + lane * 16;
-    auto dma_b = [&](int g) {          // this wave's quarter (8 x 1 KiB) of step g's weight image -> B image g & 1
-        const char* s = bsrc + (size_t)g * WF_OPER;
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.upk), 0, (unsigned)(16u * a.Cout * a.C * 4u), 0x00020000);
+    const unsigned b_vo = (unsigned)(wave * (WF_OPER / 4) + lane * 16);
+    auto dma_b = [&](int g) {          // this wave's quarter (8 x 1 KiB) of K-step g's weight image -> B image g & 1
+        const int so = (nb * a.KT + g) * WF_OPER;
         char* d = lds + WF_B_OFF + (g & 1) * WF_OPER + wave * (WF_OPER / 4);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) __builtin_amdgcn_global_load_lds((gptr_t)(s + k * 1024), (lptr_t)(d + k * 1024), 16, 0, 0);
+        for (int k = 0; k < 8; ++k) __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (lptr_t)(d + k * 1024), 16, b_vo, so + k * 1024, 0, 0);
     };
 
     // ---- patch registers of the NEXT step and the transform.  All LDS reads of the loop are asm: the compiler would put
@@ -220,7 +237,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     f32x4 P[3][4], sc, sh, rx[4], ry[4];
     sc = (f32x4){1.f, 1.f, 1.f, 1.f}; sh = (f32x4){0.f, 0.f, 0.f, 0.f};
     const unsigned ss_rd = lds0 + (unsigned)(WF_SS_OFF + q * 16);
-    auto read_patch = [&](int g) {     // 12 (+2) reads
+    auto read_patch = [&](int g) {     // 12 (+2) reads: the patch of K-step g (raw tile) and that step's scale / shift
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -264,14 +281,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(dst), "v"(o3), "n"(3 * WF_PLANE) : "memory");
     };
 
-    f32x16 acc[16];
-#pragma unroll
-    for (int p = 0; p < 16; ++p)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
-
-    // ---- prologue: A and B images of step 0 in buffers 0, raw tile of step 1 in flight
-    const int KT = a.KT;
+    // ---- prologue: geometry of item 0; A and B images of its step 0 in buffers 0, raw tile of step 1 in flight
+    dma_rec(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                    // also publishes scale / shift
+    read_slots(0);
+    read_tile(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    WF_TIE_SLOTS();
+    WF_TIE_TILE();
+    adopt_dof();
+    adopt_tile();
     dma_raw(0);
     dma_b(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -280,7 +300,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     WF_TIE_P();
     __builtin_amdgcn_s_barrier();                       // every thread has its patch of step 0: the raw tile may be overwritten
-    dma_raw(KT > 1 ? 1 : 0);
+    dma_raw(1);
 #pragma unroll
     for (int j = 0; j < 4; ++j) rows_of(j);
     planes_of(0, 0);
@@ -292,98 +312,121 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned sw = (unsigned)(((lane >> 5) ^ ((lane >> 3) & 1)) * 16);
     const unsigned a_rd = lds0 + (unsigned)(WF_A_OFF + (32 * wm + (lane & 31)) * 32) + sw;
     const unsigned b_rd = lds0 + (unsigned)(WF_B_OFF + (32 * wn + (lane & 31)) * 32) + sw;
-
-    for (int g = 0; g < KT; ++g) {
-        const unsigned cur = (unsigned)(g & 1) * WF_OPER, nxt = cur ^ WF_OPER;
-        const unsigned ab = a_rd + cur, bb = b_rd + cur;
-        const int g1 = g + 1 < KT ? g + 1 : g, g2 = g + 2 < KT ? g + 2 : KT - 1;      // past the end: valid steps again (never consumed)
-        f32x4 fa[2], fb[2];
-        asm volatile("ds_read_b128 %0, %1" : "=v"(fa[0]) : "v"(ab));
-        asm volatile("ds_read_b128 %0, %1" : "=v"(fb[0]) : "v"(bb));
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const int c = p & 1;
-            if (p < 15) {
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[c ^ 1]) : "v"(ab), "n"((p + 1) * WF_PLANE));
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[c ^ 1]) : "v"(bb), "n"((p + 1) * WF_PLANE));
-            }
-            // Side work in small pieces behind the MFMAs of the planes.  The raw tile holds step g + 1 when the step begins: read it
-            // (p = 0, behind the DMA of the weight image of step g + 1), barrier once every thread has its patch (p = 1), refill it for step
-            // g + 2 by DMA; transform (p = 2..5), A image of step g + 1 (p = 6, 7).
-            if (p == 0) {
-                if (!(ABL & 2)) dma_b(g1);          // first thing after the barrier: a whole step of cover for the weight image
-                read_patch(g1);
-                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fa[c]), "+v"(fb[c]) : "n"(XFORM ? 15 : 14));      // 4-bit field: 15 still retires this slot's fragments (issued first)
-            } else if (p == 1) {
-                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[c]), "+v"(fb[c]));                    // ... also retires the patch reads
-                WF_TIE_P();
-                __builtin_amdgcn_s_barrier();
-                if (!(ABL & 1)) dma_raw(g2);
-            } else if (p < 15) {
-                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[c]), "+v"(fb[c]));
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[c]), "+v"(fb[c]));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][e], fb[c][e], acc[p], 0, 0, 0);
-            if (p >= 2 && p < 6 && !(ABL & 4)) rows_of(p - 2);
-            if (p == 6 && !(ABL & 4)) planes_of(0, nxt);
-            if (p == 7 && !(ABL & 4)) planes_of(1, nxt);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // raw tile of step g + 2 and weight image of step g + 1 have landed
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // ... and this thread's A-image stores
-        __builtin_amdgcn_s_barrier();
-    }
-#undef WF_TIE_P
-
-    // ---- epilogue: output transform from the accumulators, bias, NHWC store, BatchNorm partial sums
     const int co = n0 + 32 * wn + (lane & 31);
     const float bv = a.bias ? a.bias[co] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
     const int WC = a.W * a.Cout;
+
+#pragma clang loop unroll(disable)
+    for (int j = 0; j < cnt; ++j) {
+        f32x16 acc[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int i = 32 * wm + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        const int2 ent = *reinterpret_cast<const int2*>(lds + WF_TAB_OFF + i * 8);
-        float r[2][4];
+        for (int p = 0; p < 16; ++p)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            r[0][j] = (acc[j][e] + acc[4 + j][e]) + acc[8 + j][e];
-            r[1][j] = (acc[4 + j][e] - acc[8 + j][e]) - acc[12 + j][e];
+            for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
+#pragma clang loop unroll(disable)
+        for (int g = 0; g < KT; ++g) {
+            // Stream step s = K-step g of item j.  It prepares step s + 1 (A image, weight image) and s + 2 (raw tile), which may
+            // belong to item j + 1: g1 / g2 are their K-steps, the geometry state (dof, pb, hi) is switched at the end of the
+            // steps KT - 3 / KT - 2.  Behind the last item the next item is the same item again (prefetched, never consumed).
+            const int jn = j + 1 < cnt ? j + 1 : j;
+            const unsigned cur = (unsigned)(g & 1) * WF_OPER, nxt = cur ^ WF_OPER;
+            const unsigned ab = a_rd + cur, bb = b_rd + cur;
+            const int g1 = g + 1 < KT ? g + 1 : 0, g2 = g + 2 < KT ? g + 2 : g + 2 - KT;
+            f32x4 fa[2], fb[2];
+            asm volatile("ds_read_b128 %0, %1" : "=v"(fa[0]) : "v"(ab));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(fb[0]) : "v"(bb));
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const int c = p & 1;
+                if (p < 15) {
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[c ^ 1]) : "v"(ab), "n"((p + 1) * WF_PLANE));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[c ^ 1]) : "v"(bb), "n"((p + 1) * WF_PLANE));
+                }
+                // Side work in small pieces behind the MFMAs of the planes.  The raw tile holds step s + 1 when the step begins: read
+                // it (p = 0, behind the DMA of the weight image of step s + 1), barrier once every thread has its patch (p = 1), refill
+                // it for step s + 2 by DMA; transform (p = 2..5), A image of step s + 1 (p = 6, 7).
+                if (p == 0) {
+                    if (!(ABL & 2)) dma_b(g1);      // first thing after the barrier: a whole step of cover for the weight image
+                    if (g == 0) dma_rec(jn, j + 1);                // next item's geometry -> the other record buffer
+                    read_patch(g1);
+                    if (g == KT - 3) read_slots(j + 1);
+                    if (g == KT - 2) read_tile(j + 1);
+                    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fa[c]), "+v"(fb[c]) : "n"(XFORM ? 15 : 14));   // 4-bit field: 15 still retires this slot's fragments (issued first)
+                } else if (p == 1) {
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[c]), "+v"(fb[c]));                    // ... also retires the patch reads
+                    WF_TIE_P();
+                    WF_TIE_SLOTS();
+                    WF_TIE_TILE();
+                    __builtin_amdgcn_s_barrier();
+                    if (!(ABL & 1)) dma_raw(g2);
+                } else if (p < 15) {
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[c]), "+v"(fb[c]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[c]), "+v"(fb[c]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][e], fb[c][e], acc[p], 0, 0, 0);
+                if (p >= 2 && p < 6 && !(ABL & 4)) rows_of(p - 2);
+                if (p == 6 && !(ABL & 4)) planes_of(0, nxt);
+                if (p == 7 && !(ABL & 4)) planes_of(1, nxt);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // raw tile of step s + 2, weight image of step s + 1 (, record) have landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // ... and this thread's A-image stores
+            __builtin_amdgcn_s_barrier();
+            if (g == KT - 3) adopt_dof();           // from the next step on the raw-tile DMA fetches item j + 1
+            if (g == KT - 2) adopt_tile();          // from the next step on the patch reads / masks are item j + 1's
         }
-        float* zp = a.z + ent.x + co;
+
+        // ---- output transform of item j from the accumulators, bias, NHWC store, BatchNorm partial sums
+        const int mb = mb0 + j * mbstep;
+        const char* rec = lds + WF_REC_OFF + (j & 1) * WF_REC_BYTES + WF_SLOTS * 4;
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int aa = 0; aa < 2; ++aa) {
-            const float y0 = ((r[aa][0] + r[aa][1]) + r[aa][2]) + bv;
-            const float y1 = ((r[aa][1] - r[aa][2]) - r[aa][3]) + bv;
-            const bool rowok = (ent.y & 1) && (aa == 0 || (ent.y & 2));
-            if (rowok) {
-                zp[aa * WC] = y0;
-                s1 += y0; s2 += y0 * y0;
-                if (ent.y & 4) {
-                    zp[aa * WC + a.Cout] = y1;
-                    s1 += y1; s2 += y1 * y1;
+        for (int e = 0; e < 16; ++e) {
+            const int i = 32 * wm + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            const int2 ent = *reinterpret_cast<const int2*>(rec + i * 16 + 8);      // {masks, output pixel}
+            float r[2][4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                r[0][jj] = (acc[jj][e] + acc[4 + jj][e]) + acc[8 + jj][e];
+                r[1][jj] = (acc[4 + jj][e] - acc[8 + jj][e]) - acc[12 + jj][e];
+            }
+            float* zp = a.z + (size_t)ent.y * a.Cout + co;
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa) {
+                const float y0 = ((r[aa][0] + r[aa][1]) + r[aa][2]) + bv;
+                const float y1 = ((r[aa][1] - r[aa][2]) - r[aa][3]) + bv;
+                const bool rowok = ((ent.x >> 8) & 1) && (aa == 0 || ((ent.x >> 9) & 1));
+                if (rowok) {
+                    if (!(ABL & 8)) zp[aa * WC] = y0;
+                    s1 += y0; s2 += y0 * y0;
+                    if ((ent.x >> 10) & 1) {
+                        if (!(ABL & 8)) zp[aa * WC + a.Cout] = y1;
+                        s1 += y1; s2 += y1 * y1;
+                    }
                 }
             }
         }
-    }
-    if (a.stats != nullptr) {
-        s1 += __shfl_xor(s1, 32, 64);
-        s2 += __shfl_xor(s2, 32, 64);
-        float* red = reinterpret_cast<float*>(lds + WF_RED_OFF);
-        if (lane < 32) { red[(wm * 64 + 32 * wn + lane) * 2] = s1; red[(wm * 64 + 32 * wn + lane) * 2 + 1] = s2; }
-        __syncthreads();
-        if (tid < 64) {
-            float* o = a.stats + ((size_t)mb * a.Cout + n0 + tid) * 2;
-            o[0] = red[tid * 2] + red[(64 + tid) * 2];
-            o[1] = red[tid * 2 + 1] + red[(64 + tid) * 2 + 1];
+        if (a.stats != nullptr) {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            float* red = reinterpret_cast<float*>(lds + WF_RED_OFF);
+            if (lane < 32) { red[(wm * 64 + 32 * wn + lane) * 2] = s1; red[(wm * 64 + 32 * wn + lane) * 2 + 1] = s2; }
+            __syncthreads();
+            if (tid < 64) {
+                float* o = a.stats + ((size_t)mb * a.Cout + n0 + tid) * 2;
+                o[0] = red[tid * 2] + red[(64 + tid) * 2];
+                o[1] = red[tid * 2 + 1] + red[(64 + tid) * 2 + 1];
+            }
         }
+        __syncthreads();          // the record of item j (and the stats exchange) may be overwritten from here on
     }
+#undef WF_TIE_P
+#undef WF_TIE_SLOTS
+#undef WF_TIE_TILE
 }
-
-unsigned wf_magic(int d) { return (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); }
 
 }  // namespace
 
@@ -412,51 +455,71 @@ int ssdhip_wino_fused_stat_rows(int N, int H, int W) {
     return (int)((T + WF_TILES - 1) / WF_TILES);
 }
 
+int64_t ssdhip_wino_fused_geo_bytes(int N, int H, int W) {
+    const int rows = ssdhip_wino_fused_stat_rows(N, H, W);
+    if (rows < 0) return SSDHIP_EINVAL;
+    return (int64_t)rows * WF_REC_BYTES;
+}
+
+int ssdhip_wino_fused_geo(int N, int H, int W, void* geo, void* stream) {
+    SSDHIP_REQUIRE(geo && N > 0 && H > 0 && W > 0, "wino_fused_geo: bad arguments");
+    const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+    SSDHIP_REQUIRE(TW >= 5 && (int64_t)N * H * W < (1ll << 31), "wino_fused_geo: map too narrow (W >= 9) or too large");
+    const int MB = ssdhip_wino_fused_stat_rows(N, H, W);
+    SSDHIP_REQUIRE(MB > 0, "wino_fused_geo: bad shape");
+    hipLaunchKernelGGL(wino_fused_geo_kernel, dim3(MB), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<int*>(geo), H, W, TH, TW,
+                       N * TH * TW, N * TH);
+    SSDHIP_CHECK_LAUNCH();
+    return SSDHIP_OK;
+}
+
 int ssdhip_wino_fused_conv(const float* x, const float* upk, const float* bias, const float* in_scale, const float* in_shift, float* z,
-                           float* stats, int N, int H, int W, int Cin, int Cout, void* stream) {
-    SSDHIP_REQUIRE(x && upk && z && N > 0 && H > 0 && W > 0, "wino_fused_conv: bad arguments");
-    SSDHIP_REQUIRE(Cin > 0 && Cin % 16 == 0 && Cin <= WF_MAXC && Cout > 0 && Cout % WF_COUT == 0,
-                   "wino_fused_conv: Cin must be a multiple of 16 (<= 1024) and Cout of 64");
+                           float* stats, const void* geo, int N, int H, int W, int Cin, int Cout, void* stream) {
+    SSDHIP_REQUIRE(x && upk && z && geo && N > 0 && H > 0 && W > 0, "wino_fused_conv: bad arguments");
+    SSDHIP_REQUIRE(Cin >= 32 && Cin % 16 == 0 && Cin <= WF_MAXC && Cout > 0 && Cout % WF_COUT == 0,
+                   "wino_fused_conv: Cin must be a multiple of 16 in 32..512 and Cout a multiple of 64");
     SSDHIP_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "wino_fused_conv: in_scale and in_shift go together");
     SSDHIP_REQUIRE((int64_t)N * H * W * Cin * 4 < (1ll << 31) && (int64_t)N * H * W * Cout < (1ll << 31),
                    "wino_fused_conv: tensors must stay below 2 GiB (32-bit offsets)");
-    const int TH = (H + 1) / 2, TW = (W + 1) / 2;
-    // 64 consecutive tiles touch at most 16 tile rows (raw tile: 512 + 8 slots per segment <= 640) and the fast divisions hold
-    SSDHIP_REQUIRE(TW >= 5 && (int64_t)N * TH < 65536, "wino_fused_conv: map too narrow (W >= 9) or too many tile rows");
-    static DeviceOnce attr;
-    if (const int dev = attr.pending(); dev != DeviceOnce::kDone) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) != hipSuccess) {
-            ssdhip_set_error("wino_fused_conv: cannot enable 158 KiB dynamic LDS");
-            return SSDHIP_ELAUNCH;
-        }
-        attr.mark(dev);
-    }
+    SSDHIP_REQUIRE((W + 1) / 2 >= 5, "wino_fused_conv: map too narrow (W >= 9)");
     int abl = 0;
 #ifdef SSDHIP_PROBES
     if (const char* e = getenv("SSDHIP_WF_ABL")) abl = atoi(e);      // probe library only (scripts/wf_bench.py)
 #endif
+    static DeviceOnce attr;
+    if (const int dev = attr.pending(); dev != DeviceOnce::kDone) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) != hipSuccess) {
+            ssdhip_set_error("wino_fused_conv: cannot enable 160 KiB dynamic LDS");
+            return SSDHIP_ELAUNCH;
+        }
+        attr.mark(dev);
+    }
     WfArgs a;
     a.x = x; a.upk = upk; a.bias = bias; a.scale = in_scale; a.shift = in_shift; a.z = z; a.stats = stats;
-    a.H = H; a.W = W; a.C = Cin; a.Cout = Cout; a.TH = TH; a.TW = TW;
-    a.T = N * TH * TW; a.KT = Cin / WF_BK; a.NB = Cout / WF_COUT; a.RT = N * TH;
+    a.geo = reinterpret_cast<const int*>(geo);
+    a.H = H; a.W = W; a.C = Cin; a.Cout = Cout;
+    a.KT = Cin / WF_BK; a.NB = Cout / WF_COUT;
+    a.MB = ssdhip_wino_fused_stat_rows(N, H, W);
+    SSDHIP_REQUIRE(a.MB > 0 && a.NB <= 256, "wino_fused_conv: bad shape");
     a.x_bytes = (unsigned)((int64_t)N * H * W * Cin * 4);
-    a.magic_tw = wf_magic(TW); a.magic_th = wf_magic(TH);
-    const int MB = (a.T + WF_TILES - 1) / WF_TILES;
-    dim3 grid((unsigned)((int64_t)MB * a.NB)), block(256);
+    // persistent grid: one block per CU, a multiple of NB so that a block keeps its channel tile (and its weight slice in L2)
+    const int64_t items = (int64_t)a.MB * a.NB;
+    int G = items < 256 ? (int)items : 256 / a.NB * a.NB;
+    dim3 grid((unsigned)G), block(256);
     hipStream_t st = (hipStream_t)stream;
 #ifdef SSDHIP_PROBES
 #define WF_ABL_CASE(k) case k: { static DeviceOnce once; if (const int d = once.pending(); d != DeviceOnce::kDone) { \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<true, k>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS); once.mark(d); } \
-        hipLaunchKernelGGL((wino_fused_kernel<true, k>), grid, block, WF_LDS, st, a); SSDHIP_CHECK_LAUNCH(); return MB; }
-    if (abl && in_scale) switch (abl) { WF_ABL_CASE(1) WF_ABL_CASE(2) WF_ABL_CASE(3) WF_ABL_CASE(4) WF_ABL_CASE(7) default: break; }
+        hipLaunchKernelGGL((wino_fused_kernel<true, k>), grid, block, WF_LDS, st, a); SSDHIP_CHECK_LAUNCH(); return a.MB; }
+    if (abl && in_scale) switch (abl) { WF_ABL_CASE(1) WF_ABL_CASE(2) WF_ABL_CASE(4) WF_ABL_CASE(7) WF_ABL_CASE(8) WF_ABL_CASE(16) WF_ABL_CASE(24) default: break; }
 #undef WF_ABL_CASE
 #endif
     (void)abl;
     if (in_scale) hipLaunchKernelGGL(wino_fused_kernel<true>, grid, block, WF_LDS, st, a);
     else hipLaunchKernelGGL(wino_fused_kernel<false>, grid, block, WF_LDS, st, a);
     SSDHIP_CHECK_LAUNCH();
-    return MB;      // rows of the BatchNorm partial table
+    return a.MB;      // rows of the BatchNorm partial table
 }
 
 }  // extern "C"

@@ -199,12 +199,22 @@ class Engine:
         self._bufs[key] = b
         return b
 
+    def _wf_geo(self, b, N, h, w, dev):
+        """Tile-block geometry table of an (N, h, w) map for the fused Winograd kernel: filled once per buffer set and shape."""
+        tab = b.setdefault('wf_geo', {})
+        t = tab.get((h, w))
+        if t is None:
+            t = torch.empty(_lib.check(self.lib.ssdhip_wino_fused_geo_bytes(N, h, w), 'wino_fused_geo_bytes'), device=dev, dtype=torch.uint8)
+            _lib.check(self.lib.ssdhip_wino_fused_geo(N, h, w, _lib.ptr(t), _lib.stream()), 'wino_fused_geo')
+            tab[(h, w)] = t
+        return t
+
     def _fused_ok(self, c, g, N):
         """Layers that run on the fused Winograd kernel: 3x3/s1/p1, wide maps (>= 70 px: from the 38x38 maps down the three-pass form
         is faster), channel counts the kernel tiles (Cin % 16, Cout % 64), tensors within its 32-bit offsets; fp32 mode only."""
         if self.bf16 or c.is_head or os.environ.get('SSD_NO_FUSED_WINOGRAD') == '1':
             return False
-        return (c.k == 3 and c.stride == 1 and c.pad == 1 and c.cin % 16 == 0 and c.cin <= 1024 and c.cout % 64 == 0
+        return (c.k == 3 and c.stride == 1 and c.pad == 1 and c.cin % 16 == 0 and 32 <= c.cin <= 512 and c.cout % 64 == 0
                 and min(g['hi'], g['wi']) >= 70 and N * g['hi'] * g['wi'] * max(c.cin * 4, c.cout) < (1 << 31)
                 and N * ((g['hi'] + 1) // 2) < 65536)
 
@@ -457,7 +467,8 @@ class Engine:
                     rows = _lib.check(self.lib.ssdhip_wino_fused_conv(_lib.ptr(cur), _lib.ptr(c.wf_img), _lib.ptr(b1) if b1 is not None else None,
                                                                       _lib.ptr(cur_xs[0]) if cur_xs is not None else None,
                                                                       _lib.ptr(cur_xs[1]) if cur_xs is not None else None, _lib.ptr(z),
-                                                                      _lib.ptr(ws['partial']) if training else None, N, g['hi'], g['wi'],
+                                                                      _lib.ptr(ws['partial']) if training else None,
+                                                                      _lib.ptr(self._wf_geo(b, N, g['hi'], g['wi'], dev)), N, g['hi'], g['wi'],
                                                                       c.cin, c.cout, st), f'conv2d {c.name}')
                 elif c.wino and self._wino_ok(g) and not self.bf16:     # bf16 MFMA outruns the fp32 Winograd pipeline: direct kernel
                     rows = self._conv_winograd(c, cur, cur_xs, z, ws, N, g['hi'], g['wi'], ws['partial'] if training else None)

@@ -105,6 +105,23 @@ def wino_fused_pack(w_oihw):
     return upk
 
 
+_wf_geo = {}
+
+
+def wino_fused_geo(N, H, W, device):
+    """Tile-block geometry table of an (N, H, W) map for the fused Winograd kernel (cached per shape and device)."""
+    key = (N, H, W, str(device))
+    g = _wf_geo.get(key)
+    if g is None:
+        lib = _lib.load()
+        g = torch.empty(_lib.check(lib.ssdhip_wino_fused_geo_bytes(N, H, W), 'wino_fused_geo_bytes'), device=device, dtype=torch.uint8)
+        _lib.check(lib.ssdhip_wino_fused_geo(N, H, W, _lib.ptr(g), _lib.stream()), 'wino_fused_geo')
+        if len(_wf_geo) >= 8:
+            _wf_geo.pop(next(iter(_wf_geo)))
+        _wf_geo[key] = g
+    return g
+
+
 def wino_fused_conv(x, w_oihw, bias=None, in_scale=None, in_shift=None, want_stats=False, upk=None):
     """3x3/s1/p1 conv as ONE fused Winograd F(2x2,3x3) kernel: x (N,H,W,Cin) NHWC -> (z (N,H,W,Cout), stats (MB,Cout,2) or None)."""
     _lib.require_gpu(x, w_oihw)
@@ -121,7 +138,8 @@ def wino_fused_conv(x, w_oihw, bias=None, in_scale=None, in_shift=None, want_sta
     _lib.check(lib.ssdhip_wino_fused_conv(_lib.ptr(x), _lib.ptr(upk), _lib.ptr(bias) if bias is not None else None,
                                           _lib.ptr(in_scale) if in_scale is not None else None,
                                           _lib.ptr(in_shift) if in_shift is not None else None, _lib.ptr(z),
-                                          _lib.ptr(stats) if stats is not None else None, N, H, W, C, cout, _lib.stream()), 'wino_fused_conv')
+                                          _lib.ptr(stats) if stats is not None else None, _lib.ptr(wino_fused_geo(N, H, W, x.device)),
+                                          N, H, W, C, cout, _lib.stream()), 'wino_fused_conv')
     return z, stats
 
 
