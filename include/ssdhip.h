@@ -138,6 +138,14 @@ int ssdhip_match_mask(const float* targets, const float* dboxes, int N, int P, i
 int ssdhip_decode_score(float* outputs, const float* dboxes, int N, int P, int C, void* stream);
 /* ---- A21  utils.calc_iou (utils.py:58-77): t (N,T,rowt), s (N,S,rows) -> (N,T,S) ------------------------- */
 int ssdhip_calc_iou(const float* t, const float* s, int N, int T, int S, int rowt, int rows, float* iou, void* stream);
+/* ---- 8(f)-1  true-positive assignment of the evaluation loop (evaluate.py:134-151) on decoded, scored, NMS-filtered
+ * outputs (N,P,4+C) (one positive score column per row, as utils.calc_score leaves them) and gts (N,G,4+C) one-hot rows:
+ * cls (N,P) int32 = class of the row's positive score (column 5 + cls) or -1; tp (N,P) uint8 = 1 where the row is the
+ * highest-scored claimant (IoU > iou_thresh with its best-IoU ground truth of the same class) of that ground truth;
+ * score (N,P) fp32, may be NULL: that positive score (0 where cls = -1);
+ * gt_count (C-1) int32, may be NULL: += number of ground-truth rows per class (evaluate.py:138-151 result_count).        */
+int ssdhip_eval_match(const float* outputs, const float* gts, int N, int P, int G, int C, float iou_thresh, int32_t* cls, uint8_t* tp,
+                      float* score, int32_t* gt_count, void* stream);
 /* ---- A22  utils.non_maximum_suppression (utils.py:80-116): greedy, class-agnostic, strict '>' -------------
  * outputs (N,P,4+C) decoded+scored; zeroes outputs[n,p,4:] of suppressed / void rows in place.
  * keep (N,P) uint8 (optional, may be NULL).  P <= 9000 (all-LDS).                                                   */

@@ -63,6 +63,8 @@ SIGNATURES = {
     'ssdhip_match_mask': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     'ssdhip_decode_score': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'ssdhip_calc_iou': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'ssdhip_eval_match': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p]),
     'ssdhip_nms': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     'ssdhip_nms_ws_bytes': (c_int64, [c_int, c_int]),
     'ssdhip_nms_ws': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),

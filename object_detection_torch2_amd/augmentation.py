@@ -8,9 +8,13 @@ stays a uint8 HWC array inside a `Deferred`.  `utils.collate_fn` stacks a batch 
 `.to(device)` -- the call the training loop already makes (train.py:106) -- uploads 1 byte per channel instead of 4 and
 runs the whole pipeline as one HIP pass over the batch (`ssdhip_augment_batch`, csrc/augment.hip).
 
-The sampling rules restate torchvision's `ColorJitter.get_params` / `RandomErasing.get_params` (the reference subclasses
-them); torchvision is not installed here, so they are checked against the published definitions, not against the library
-("parity unpinned").  Random draws use torch's global generator like the reference (torch.manual_seed controls them)."""
+Pixel arithmetic = the backend the reference really runs: RandomColorJitter comes BEFORE ToTensor (train.py:32-36), so
+torchvision's ColorJitter works on the PIL image (PIL.ImageEnhance + an HSV round trip, uint8 after every operation).
+Pillow is importable in the build container: the device pass is pinned bit for bit by PIL's own outputs (tests/golden G12).
+The SAMPLING rules restate torchvision's `ColorJitter.get_params` / `RandomErasing.get_params` (the reference subclasses
+them); torchvision itself is not installed here, so the order / number of random draws follows its published source, not a
+run of the library ("parity unpinned" for the draws; the pixels are pinned).  Random draws use torch's global generator
+like the reference (torch.manual_seed controls them)."""
 import math
 
 import numpy as np
@@ -97,7 +101,10 @@ class RandomColorJitter:
             img.row[0] = 4
             img.row[1:5] = order.numpy()
             for op, (lo, hi) in enumerate(self.ranges):
-                img.row[5 + op] = _uniform(lo, hi)
+                f = _uniform(lo, hi)
+                # hue travels as torchvision's uint8 shift of PIL's H channel: np.uint8(hue_factor * 255), computed in double,
+                # truncated toward zero, wrapped (adjust_hue: "uint8 addition take cares of rotation across boundaries")
+                img.row[5 + op] = f if op < 3 else float(int(f * 255) & 255)
         return img, gt
 
 

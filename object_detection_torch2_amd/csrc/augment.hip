@@ -3,75 +3,96 @@
 // flip, uint8 -> [0,1] float (ToTensor) and up to three erased rectangles, as two HBM-bound passes over the batch.
 // The host only samples the per-image parameters (augmentation.py); pixels are touched here, once.
 //
-// Pixel math follows torchvision's tensor path, which the reference's ColorJitter/RandomErasing subclasses inherit
-// (torchvision is not importable in this image, so this row is "parity unpinned"; the oracle restates the same formulas):
-//   blend(a, b, f) = clamp(f a + (1 - f) b, 0, 1);  gray = 0.2989 r + 0.587 g + 0.114 b
-//   brightness: blend(x, 0, f)   contrast: blend(x, mean(gray(x)), f)   saturation: blend(x, gray(x), f)
-//   hue: rgb -> hsv, h = (h + f) mod 1, hsv -> rgb
+// Pixel math follows the backend the reference really runs: train.py:32-36 puts RandomColorJitter BEFORE ToTensor, so
+// torchvision's ColorJitter works on the PIL image -- PIL.ImageEnhance for brightness / contrast / saturation and an HSV round
+// trip for hue, every operation quantised back to uint8.  PIL is importable in the build container, so this row is pinned:
+// tests/golden/g12_augment_pil.npz holds PIL's own outputs (tests/golden/make_golden.py), and the HSV conversions below were
+// compared with PIL over all 2^24 colours.
+//   Image.blend(d, x, f) per byte, in float: t = d + f (x - d); 0 <= f <= 1: (uint8) t, else clip to [0, 255] then truncate
+//   brightness: d = 0;  contrast: d = int(mean(L(x)) + 0.5);  saturation: d = L(x);  L = (19595 r + 38470 g + 7471 b + 32768) >> 16
+//   hue: RGB -> HSV (PIL's rgb2hsv: float / double mix as in its C source), h = (h + shift) mod 256, HSV -> RGB
+// then horizontal flip, uint8 -> [0,1] float (ToTensor: x / 255) and up to three erased rectangles.
 // Parameter row per image (AUG_ROW floats): [0] number of colour ops (0 or 4), [1..4] op ids in application order
-// (0 brightness, 1 contrast, 2 saturation, 3 hue), [5..8] factor of op id 0..3, [9] flip, [10] number of erase boxes (<= 3),
-// [11 + 4k ..] box k as (top, left, height, width) in pixels of the (flipped) output image.
+// (0 brightness, 1 contrast, 2 saturation, 3 hue), [5..7] factor of op id 0..2, [8] hue shift in 1/255 turns as an integer 0..255
+// (= uint8(int(hue_factor * 255)), computed by the host in double like torchvision does), [9] flip, [10] number of erase boxes
+// (<= 3), [11 + 4k ..] box k as (top, left, height, width) in pixels of the (flipped) output image.
 #include "common.h"
 
 namespace {
 
 constexpr int AUG_ROW = 24, MEAN_BLOCKS = 64;
 
-struct RGB { float r, g, b; };
+struct RGB { int r, g, b; };          // uint8 values
 
-__device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
-__device__ __forceinline__ float gray_of(RGB p) { return 0.2989f * p.r + 0.587f * p.g + 0.114f * p.b; }
-__device__ __forceinline__ RGB blend(RGB a, float br, float bg, float bb, float f) {
-    return {clamp01(f * a.r + (1.f - f) * br), clamp01(f * a.g + (1.f - f) * bg), clamp01(f * a.b + (1.f - f) * bb)};
+__device__ __forceinline__ int luma(RGB p) { return (p.r * 19595 + p.g * 38470 + p.b * 7471 + 0x8000) >> 16; }
+// PIL ImagingBlend on one byte: float arithmetic, product rounded before the sum (this file is compiled with -ffp-contract=off)
+__device__ __forceinline__ int blend1(int d, int x, float f, bool inside) {
+    const float t = (float)d + f * (float)(x - d);
+    if (inside) return (int)t;
+    return t <= 0.f ? 0 : t >= 255.f ? 255 : (int)t;
 }
+__device__ __forceinline__ RGB blend(RGB d, RGB x, float f) {
+    const bool inside = f >= 0.f && f <= 1.f;
+    return {blend1(d.r, x.r, f, inside), blend1(d.g, x.g, f, inside), blend1(d.b, x.b, f, inside)};
+}
+__device__ __forceinline__ int clip8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
 
-__device__ __forceinline__ RGB shift_hue(RGB p, float hf) {
-    const float maxc = fmaxf(p.r, fmaxf(p.g, p.b)), minc = fminf(p.r, fminf(p.g, p.b));
-    const bool eq = maxc == minc;
-    const float cr = maxc - minc;
-    const float s = cr / (eq ? 1.f : maxc);
-    const float div = eq ? 1.f : cr;
-    const float rc = (maxc - p.r) / div, gc = (maxc - p.g) / div, bc = (maxc - p.b) / div;
-    float h;
-    if (maxc == p.r) h = bc - gc;
-    else if (maxc == p.g) h = 2.f + rc - bc;
-    else h = 4.f + gc - rc;
-    h = fmodf(h / 6.f + 1.f, 1.f);
-    h = h + hf;
-    h = h - floorf(h);                                   // python-style mod 1
-    const float v = maxc;
-    const float h6 = h * 6.f, fl = floorf(h6), f = h6 - fl;
-    int i = (int)fl % 6;
-    const float pp = clamp01(v * (1.f - s)), q = clamp01(v * (1.f - s * f)), t = clamp01(v * (1.f - s * (1.f - f)));
-    switch (i) {
-        case 0: return {v, t, pp};
-        case 1: return {q, v, pp};
-        case 2: return {pp, v, t};
-        case 3: return {pp, q, v};
-        case 4: return {t, pp, v};
-        default: return {v, pp, q};
+__device__ __forceinline__ RGB shift_hue(RGB p, int shift) {
+    // PIL rgb2hsv_row
+    const int maxc = max(p.r, max(p.g, p.b)), minc = min(p.r, min(p.g, p.b));
+    int uh = 0, us = 0;
+    const int uv = maxc;
+    if (minc != maxc) {
+        const float cr = (float)(maxc - minc);
+        const float sat = cr / (float)maxc;
+        const float rc = (float)(maxc - p.r) / cr, gc = (float)(maxc - p.g) / cr, bc = (float)(maxc - p.b) / cr;
+        float h;
+        if (p.r == maxc) h = bc - gc;
+        else if (p.g == maxc) h = (float)(2.0 + (double)rc - (double)bc);
+        else h = (float)(4.0 + (double)gc - (double)rc);
+        h = (float)fmod((double)h / 6.0 + 1.0, 1.0);
+        uh = clip8((int)((double)h * 255.0));
+        us = clip8((int)((double)sat * 255.0));
+    }
+    uh = (uh + shift) & 255;             // uint8 addition "takes care of rotation across boundaries" (torchvision adjust_hue)
+    // PIL hsv2rgb
+    if (us == 0) return {uv, uv, uv};
+    const double hh = (double)(float)uh * 6.0 / 255.0;
+    const double fl = floor(hh);
+    const float f = (float)(hh - (double)(float)fl);
+    const float fs = (float)((double)(float)us / 255.0);
+    const double vf = (double)(float)uv;
+    const int pp = clip8((int)floor(vf * (1.0 - (double)fs) + 0.5));
+    const int q = clip8((int)floor(vf * (1.0 - (double)fs * (double)f) + 0.5));
+    const int t = clip8((int)floor(vf * (1.0 - (double)fs * (1.0 - (double)f)) + 0.5));
+    switch ((int)fl % 6) {
+        case 0: return {uv, t, pp};
+        case 1: return {q, uv, pp};
+        case 2: return {pp, uv, t};
+        case 3: return {pp, q, uv};
+        case 4: return {t, pp, uv};
+        default: return {uv, pp, q};
     }
 }
 
 // colour ops [0, upto) of the image's order; `mean` is only read by a contrast op inside that range
-__device__ __forceinline__ RGB colour_chain(RGB p, const float* __restrict__ prm, int upto, float mean) {
+__device__ __forceinline__ RGB colour_chain(RGB p, const float* __restrict__ prm, int upto, int mean) {
     for (int k = 0; k < upto; ++k) {
         const int op = (int)prm[1 + k] & 3;
-        const float f = prm[5 + op];
-        if (op == 0) p = blend(p, 0.f, 0.f, 0.f, f);
-        else if (op == 1) p = blend(p, mean, mean, mean, f);
-        else if (op == 2) { const float g = gray_of(p); p = blend(p, g, g, g, f); }
-        else p = shift_hue(p, f);
+        if (op == 0) p = blend({0, 0, 0}, p, prm[5]);
+        else if (op == 1) p = blend({mean, mean, mean}, p, prm[6]);
+        else if (op == 2) { const int g = luma(p); p = blend({g, g, g}, p, prm[7]); }
+        else p = shift_hue(p, (int)prm[8] & 255);
     }
     return p;
 }
 
 __device__ __forceinline__ RGB load_u8(const uint8_t* __restrict__ src, size_t pix) {
     const uint8_t* q = src + pix * 3;
-    return {q[0] / 255.f, q[1] / 255.f, q[2] / 255.f};
+    return {q[0], q[1], q[2]};
 }
 
-// pass 1: per-image partial sums of gray(x after the ops that precede contrast); fixed slices, fp64, deterministic
+// pass 1: per-image partial sums of L(x after the ops that precede contrast): integers, fixed slices -> exact and deterministic
 __global__ __launch_bounds__(256) void augment_mean_kernel(const uint8_t* __restrict__ src, const float* __restrict__ params, int HW,
                                                            double* __restrict__ partial) {
     const int n = blockIdx.y;
@@ -80,10 +101,10 @@ __global__ __launch_bounds__(256) void augment_mean_kernel(const uint8_t* __rest
     int cpos = -1;
     for (int k = 0; k < nops; ++k)
         if (((int)prm[1 + k] & 3) == 1) cpos = k;
-    double acc = 0.0;
+    double acc = 0.0;                                    // sums of at most 2^30 bytes: exact in a double
     if (cpos >= 0) {
         const int per = (HW + MEAN_BLOCKS - 1) / MEAN_BLOCKS, lo = blockIdx.x * per, hi = min(HW, lo + per);
-        for (int i = lo + threadIdx.x; i < hi; i += 256) acc += (double)gray_of(colour_chain(load_u8(src, (size_t)n * HW + i), prm, cpos, 0.f));
+        for (int i = lo + threadIdx.x; i < hi; i += 256) acc += (double)luma(colour_chain(load_u8(src, (size_t)n * HW + i), prm, cpos, 0));
     }
     __shared__ double red[4];
     acc = wave_sum_d(acc);
@@ -97,11 +118,11 @@ __global__ __launch_bounds__(256) void augment_apply_kernel(const uint8_t* __res
                                                             const double* __restrict__ partial, int H, int W, float* __restrict__ out) {
     const int n = blockIdx.y, HW = H * W;
     const float* prm = params + (size_t)n * AUG_ROW;
-    __shared__ float s_mean;
+    __shared__ int s_mean;
     if (threadIdx.x == 0) {
         double s = 0.0;
         for (int i = 0; i < MEAN_BLOCKS; ++i) s += partial[(size_t)n * MEAN_BLOCKS + i];
-        s_mean = (float)(s / (double)HW);
+        s_mean = (int)(s / (double)HW + 0.5);            // ImageEnhance.Contrast: int(ImageStat.Stat(L).mean[0] + 0.5)
     }
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -113,10 +134,10 @@ __global__ __launch_bounds__(256) void augment_apply_kernel(const uint8_t* __res
     const int ne = min((int)prm[10], 3);
     for (int k = 0; k < ne; ++k) {
         const int top = (int)prm[11 + 4 * k], left = (int)prm[12 + 4 * k], h = (int)prm[13 + 4 * k], w = (int)prm[14 + 4 * k];
-        if (y >= top && y < top + h && x >= left && x < left + w) p = {0.f, 0.f, 0.f};
+        if (y >= top && y < top + h && x >= left && x < left + w) p = {0, 0, 0};
     }
     float* o = out + (size_t)n * 3 * HW + i;
-    o[0] = p.r; o[HW] = p.g; o[2 * (size_t)HW] = p.b;
+    o[0] = (float)p.r / 255.f; o[HW] = (float)p.g / 255.f; o[2 * (size_t)HW] = (float)p.b / 255.f;          // ToTensor
 }
 
 }  // namespace

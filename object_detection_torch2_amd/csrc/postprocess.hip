@@ -98,6 +98,65 @@ __global__ void calc_iou_kernel(const float* __restrict__ t, const float* __rest
     iou[((size_t)n * T + ti) * S + si] = iou_val(tp, sp);
 }
 
+// True-positive assignment of the evaluation loop (evaluate.py:134-151), one block per image.  In the reference, per class c:
+// predictions with a positive class-c score in descending score order, GT rows of class c; every prediction claims its best-IoU
+// GT (first maximum) if IoU > thr; of the claimants of a GT only the first in score order is a true positive
+// ((valid.cumsum(0) == valid) * valid).  After utils.calc_score every row has exactly one positive score column, so the classes
+// partition the predictions and all of them are handled in one pass: the winner of a GT is found by a 64-bit atomic max on
+// (score bits, ~row), i.e. highest score, ties to the lower row (the reference's torch.sort leaves ties unspecified).
+__global__ __launch_bounds__(1024) void eval_match_kernel(const float* __restrict__ outputs, const float* __restrict__ gts, int P, int G,
+                                                          int C, float thr, int* __restrict__ cls, uint8_t* __restrict__ tp,
+                                                          float* __restrict__ score, int* __restrict__ gt_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* win = reinterpret_cast<unsigned long long*>(smem);          // G winners
+    float* gbox = reinterpret_cast<float*>(smem + (size_t)G * 8);                    // G x 4
+    int* gcls = reinterpret_cast<int*>(smem + (size_t)G * 24);                       // G
+    const int n = blockIdx.x, row = 4 + C;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        const float* t = gts + ((size_t)n * G + g) * row;
+        int c = -1;
+        for (int k = 0; k < C - 1; ++k)
+            if (t[5 + k] > 0.f) { c = k; break; }
+        gcls[g] = c;
+        gbox[4 * g] = t[0]; gbox[4 * g + 1] = t[1]; gbox[4 * g + 2] = t[2]; gbox[4 * g + 3] = t[3];
+        win[g] = 0ull;
+        if (c >= 0 && gt_count) atomicAdd(&gt_count[c], 1);
+    }
+    __syncthreads();
+    auto claim = [&](int p, int& c, unsigned long long& key) -> int {      // class / key of prediction p; returns its claimed GT or -1
+        const float* o = outputs + ((size_t)n * P + p) * row;
+        c = -1;
+        float score = 0.f;
+        for (int k = 0; k < C - 1; ++k)
+            if (o[5 + k] > 0.f) { c = k; score = o[5 + k]; break; }
+        if (c < 0) return -1;
+        int best = -1;
+        float biou = 0.f;
+        for (int g = 0; g < G; ++g) {
+            if (gcls[g] != c) continue;
+            const float v = iou_val(o, gbox + 4 * g);
+            if (best < 0 || v > biou) { best = g; biou = v; }
+        }
+        key = ((unsigned long long)__float_as_uint(score) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)p);
+        return (best >= 0 && biou > thr) ? best : -1;
+    };
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+        int c;
+        unsigned long long key;
+        const int g = claim(p, c, key);
+        if (g >= 0) atomicMax(&win[g], key);
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+        int c;
+        unsigned long long key = 0;
+        const int g = claim(p, c, key);
+        cls[(size_t)n * P + p] = c;
+        tp[(size_t)n * P + p] = (g >= 0 && win[g] == key) ? 1 : 0;
+        if (score) score[(size_t)n * P + p] = c >= 0 ? __uint_as_float((unsigned)(key >> 32)) : 0.f;
+    }
+}
+
 constexpr int NMS_THREADS = 1024;
 constexpr int NMS_WAVES = NMS_THREADS / 64;
 constexpr int NMS_LDS_BYTES = 160 * 1024;
@@ -593,6 +652,16 @@ int ssdhip_calc_iou(const float* t, const float* s, int N, int T, int S, int row
     SSDHIP_REQUIRE(t && s && iou && N > 0 && T > 0 && S > 0 && rowt >= 4 && rows >= 4, "calc_iou: bad arguments");
     SSDHIP_REQUIRE(T <= 65535 && N <= 65535, "calc_iou: T and N must be <= 65535");
     hipLaunchKernelGGL(calc_iou_kernel, dim3(cdiv(S, 256), T, N), dim3(256), 0, (hipStream_t)stream, t, s, T, S, rowt, rows, iou);
+    SSDHIP_CHECK_LAUNCH();
+    return SSDHIP_OK;
+}
+
+int ssdhip_eval_match(const float* outputs, const float* gts, int N, int P, int G, int C, float iou_thresh, int32_t* cls, uint8_t* tp,
+                      float* score, int32_t* gt_count, void* stream) {
+    SSDHIP_REQUIRE(outputs && gts && cls && tp && N > 0 && P > 0 && G >= 0 && C >= 2, "eval_match: bad arguments");
+    SSDHIP_REQUIRE(G <= 2048, "eval_match: at most 2048 ground-truth rows per image");
+    hipLaunchKernelGGL(eval_match_kernel, dim3(N), dim3(1024), (size_t)(G > 0 ? G : 1) * 28, (hipStream_t)stream, outputs, gts, P, G, C,
+                       iou_thresh, cls, tp, score, gt_count);
     SSDHIP_CHECK_LAUNCH();
     return SSDHIP_OK;
 }

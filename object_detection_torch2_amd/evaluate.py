@@ -1,5 +1,5 @@
 """Evaluation entry point with the reference's flags (src/evaluate.py:75-81): forward -> decode -> score -> NMS ->
-IoU vs GT (evaluate.py:128-132, all on the HIP path) -> per-class greedy TP assignment (evaluate.py:134-151) -> AP.
+IoU vs GT + per-class greedy TP assignment (evaluate.py:128-151: one device pass, `ssdhip_eval_match`) -> AP on the host.
 
 `calc_average_precision(..., reference_compatible=True)` reproduces the reference's AP exactly, including its quirk:
 `torch.sort(result, dim=0)` sorts the TP column and the score column independently (evaluate.py:55), i.e. true positives
@@ -52,29 +52,49 @@ def calc_average_precision(result: torch.Tensor, count, reference_compatible: bo
     return torch.tensor(float(np.sum(envelope * steps)), dtype=torch.float32)
 
 
+def match_true_positives(outputs: torch.Tensor, gts: torch.Tensor, iou_thresh: float = 0.5, gt_count: torch.Tensor = None):
+    """evaluate.py:132-151 for a whole batch in ONE device pass (`ssdhip_eval_match`): outputs (N,P,4+C) decoded, scored and
+    NMS-filtered, gts (N,G,4+C) -> (cls (N,P) int32: class of the row's positive score or -1, tp (N,P) uint8, score (N,P)).
+    gt_count (C-1,) int32 on the device, optional: += ground-truth boxes per class."""
+    from . import _lib
+    _lib.require_gpu(outputs, gts)
+    outputs, gts = _lib.f32c(outputs), _lib.f32c(gts)
+    if outputs.dim() != 3 or gts.dim() != 3 or outputs.shape[0] != gts.shape[0] or outputs.shape[2] != gts.shape[2] or outputs.shape[2] < 6:
+        raise ValueError(f'match_true_positives: outputs {tuple(outputs.shape)} and gts {tuple(gts.shape)} must be (N, *, 4 + C), C >= 2')
+    N, P, row = outputs.shape
+    cls = torch.empty(N, P, dtype=torch.int32, device=outputs.device)
+    tp = torch.empty(N, P, dtype=torch.uint8, device=outputs.device)
+    score = torch.empty(N, P, dtype=torch.float32, device=outputs.device)
+    _lib.check(_lib.load().ssdhip_eval_match(_lib.ptr(outputs), _lib.ptr(gts), N, P, gts.shape[1], row - 4, float(iou_thresh), _lib.ptr(cls),
+                                             _lib.ptr(tp), _lib.ptr(score), _lib.ptr(gt_count) if gt_count is not None else None,
+                                             _lib.stream()), 'eval_match')
+    return cls, tp, score
+
+
 def evaluate_batches(net, defaults, batches, num_classes=20):
-    """Accumulate per-class [is_tp, score] rows and GT counts over (images, gts) device batches."""
+    """Accumulate per-class [is_tp, score] rows and GT counts over (images, gts) device batches (evaluate.py:117-151): forward,
+    decode, score, NMS and the true-positive assignment run on the device; what comes back per batch is (class, tp, score) per
+    prior, grouped per class on the host like the reference's result_correct / result_count."""
+    import numpy as np
     result_correct = {c: [] for c in range(num_classes)}
-    result_count = {c: 0 for c in range(num_classes)}
+    gt_count = None
     with torch.no_grad():
         for images, gts in batches:
             outputs = net(images)
             decode_score_(outputs, defaults)
             outputs = non_maximum_suppression(outputs=outputs)
-            ious = calc_iou(outputs, gts)
-            for output, gt, iou in zip(outputs, gts, ious):
-                for c in range(num_classes):
-                    pr_order, gt_order = get_order(output, c), get_order(gt, c)
-                    if len(pr_order) == 0:
-                        result_count[c] += len(gt_order)
+            if gt_count is None:
+                gt_count = torch.zeros(outputs.shape[2] - 5, dtype=torch.int32, device=outputs.device)
+            cls, tp, score = (t.cpu().numpy() for t in match_true_positives(outputs, gts, 0.5, gt_count))
+            for n in range(cls.shape[0]):                        # image order, then class, then descending score: the reference's row order
+                for c in np.unique(cls[n][cls[n] >= 0]):
+                    if c >= num_classes:
                         continue
-                    if len(gt_order) == 0:
-                        correct = torch.zeros(len(pr_order), 1, device=output.device)
-                    else:
-                        correct = assign_true_positives(iou[pr_order][:, gt_order])
-                    result_correct[c].append(torch.cat([correct, output[pr_order][:, [5 + c]]], dim=1))
-                    result_count[c] += len(gt_order)
-    return result_correct, result_count
+                    rows = np.nonzero(cls[n] == c)[0]
+                    rows = rows[np.argsort(-score[n, rows], kind='stable')]
+                    result_correct[int(c)].append(torch.from_numpy(np.stack([tp[n, rows].astype(np.float32), score[n, rows]], axis=1)))
+    counts = gt_count.cpu().tolist() if gt_count is not None else [0] * num_classes
+    return result_correct, {c: int(counts[c]) if c < len(counts) else 0 for c in range(num_classes)}
 
 
 def main():

@@ -295,6 +295,37 @@ def non_maximum_suppression(outputs, iou_thresh=0.5):
 
 
 # ----------------------------------------------------------------------------
+# evaluation bookkeeping (src/evaluate.py:31-42 get_order, :134-151 the per-image / per-class loop body)
+# ----------------------------------------------------------------------------
+def get_order(t, class_id):
+    """evaluate.py:31-42: rows with a positive value in column 5 + class_id, by descending value (ties: lower row first; the
+    reference's torch.sort leaves them unspecified)."""
+    v = t[:, 5 + class_id]
+    order = np.argsort(-v.astype(np.float64), kind='stable')
+    return order[v[order] > 0]
+
+
+def eval_image(output, gt, num_classes=20, iou_thresh=0.5):
+    """evaluate.py:134-151 for one image: output (P,4+C) decoded / scored / NMS-filtered, gt (G,4+C).
+    Returns ({class: (X,2) rows [correct, score] in score order}, {class: number of GT boxes})."""
+    iou = calc_iou(output[None], gt[None])[0]
+    rows, counts = {}, {}
+    for c in range(num_classes):
+        pr_order, gt_order = get_order(output, c), get_order(gt, c)
+        counts[c] = len(gt_order)
+        if len(pr_order) == 0:
+            continue
+        if len(gt_order) == 0:
+            correct = np.zeros((len(pr_order), 1), f32)
+        else:
+            iou_one = iou[pr_order][:, gt_order]
+            valid = np.eye(len(gt_order), dtype=f32)[iou_one.argmax(axis=1)] * (iou_one > f32(iou_thresh))
+            correct = ((np.cumsum(valid, axis=0) == valid) * valid).sum(axis=1, keepdims=True)
+        rows[c] = np.concatenate([correct.astype(f32), output[pr_order][:, [5 + c]]], axis=1)
+    return rows, counts
+
+
+# ----------------------------------------------------------------------------
 # A2-A8 forward on torch CPU ops (floating-point layers)
 # ----------------------------------------------------------------------------
 def init_state(seed=1, num_classes=21, vgg_random=True, imsize=300):
@@ -386,46 +417,95 @@ def train_step(sd, opt_state, images, targets_np, df, lr=1e-3, wd=5e-4, num_clas
 
 
 # ----------------------------------------------------------------------------
-# batch augmentation (src/augmentation/random.py:6-42 -> torchvision's tensor-path definitions; "parity unpinned":
-# torchvision is not importable here, the formulas below are its published ones: _blend, rgb_to_grayscale,
-# adjust_{brightness,contrast,saturation,hue}, _rgb2hsv/_hsv2rgb, erase with value 0)
+# batch augmentation (src/augmentation/random.py:6-42 as the reference runs it: train.py:32-36 puts RandomColorJitter BEFORE
+# ToTensor, i.e. torchvision's ColorJitter on a PIL image -> PIL.ImageEnhance for brightness / contrast / saturation, an HSV
+# round trip for hue, uint8 after every operation; then PIL hflip, ToTensor (x / 255) and RandomErasing with value 0).
+# torchvision is not importable here; Pillow (the third-party arithmetic: 12.2.0 in this image, unpinned by the reference) is, so
+# these restatements are pinned by PIL's own outputs: tests/golden/g12_augment_pil.npz, and the two HSV conversions were compared
+# with PIL over all 2^24 colours (tests/golden/make_golden.py gen_augment).
 # ----------------------------------------------------------------------------
-def _blend(a, b, f):
-    f = f32(f)
-    return np.clip(f * a + (f32(1) - f) * b, f32(0), f32(1)).astype(f32)
+def pil_luma(rgb):
+    """Image.convert('L'): ITU-R 601-2 luma in 16.16 fixed point."""
+    r, g, b = (rgb[..., k].astype(np.int64) for k in range(3))
+    return ((r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16).astype(np.uint8)
 
 
-def _gray(x):          # x: (H,W,3) fp32
-    return (f32(0.2989) * x[..., 0] + f32(0.587) * x[..., 1] + f32(0.114) * x[..., 2]).astype(f32)
+def pil_blend(d, x, alpha):
+    """Image.blend(d, x, alpha) on uint8 arrays (libImaging/Blend.c): float arithmetic d + alpha (x - d), truncated; outside
+    0 <= alpha <= 1 clipped to [0, 255] first.  alpha is a C float."""
+    a = f32(alpha)
+    di, xi = d.astype(np.int32), x.astype(np.int32)
+    t = (di.astype(f32) + (a * (xi - di).astype(f32)).astype(f32)).astype(f32)
+    if 0.0 <= float(a) <= 1.0:
+        return t.astype(np.int32).astype(np.uint8)
+    return np.where(t <= 0, 0, np.where(t >= 255, 255, t.astype(np.int32))).astype(np.uint8)
 
 
-def _hue(x, hf):
-    r, g, b = x[..., 0], x[..., 1], x[..., 2]
+def pil_brightness(x, f):          # ImageEnhance.Brightness: degenerate = black
+    return pil_blend(np.zeros_like(x), x, f)
+
+
+def pil_contrast(x, f):            # ImageEnhance.Contrast: degenerate = int(mean(L) + 0.5)
+    L = pil_luma(x)
+    mean = int(int(L.astype(np.int64).sum()) / L.size + 0.5)
+    return pil_blend(np.full_like(x, mean), x, f)
+
+
+def pil_saturation(x, f):          # ImageEnhance.Color: degenerate = L
+    return pil_blend(np.repeat(pil_luma(x)[..., None], 3, axis=-1), x, f)
+
+
+def pil_rgb2hsv(rgb):
+    """Image.convert('HSV') (libImaging/Convert.c rgb2hsv_row): float / double mix as in the C source."""
+    r, g, b = (rgb[..., k].astype(np.int32) for k in range(3))
     maxc, minc = np.maximum(r, np.maximum(g, b)), np.minimum(r, np.minimum(g, b))
+    cr = (maxc - minc).astype(f32)
+    crs = np.where(cr == 0, f32(1), cr)
+    s = (cr / np.where(maxc == 0, 1, maxc).astype(f32)).astype(f32)
+    rc, gc, bc = (((maxc - c).astype(f32) / crs).astype(f32) for c in (r, g, b))
+    f64 = np.float64
+    h = np.where(r == maxc, (bc - gc).astype(f32),
+                 np.where(g == maxc, (f64(2.0) + rc.astype(f64) - bc.astype(f64)).astype(f32),
+                          (f64(4.0) + gc.astype(f64) - rc.astype(f64)).astype(f32)))
+    h = np.fmod(h.astype(f64) / 6.0 + 1.0, 1.0).astype(f32)
+    uh = np.clip((h.astype(f64) * 255.0).astype(np.int32), 0, 255)
+    us = np.clip((s.astype(f64) * 255.0).astype(np.int32), 0, 255)
     eq = maxc == minc
-    cr = maxc - minc
-    s = cr / np.where(eq, f32(1), maxc)
-    div = np.where(eq, f32(1), cr)
-    rc, gc, bc = (maxc - r) / div, (maxc - g) / div, (maxc - b) / div
-    h = np.where(maxc == r, bc - gc, np.where(maxc == g, f32(2) + rc - bc, f32(4) + gc - rc)).astype(f32)
-    h = np.fmod(h / f32(6) + f32(1), f32(1)).astype(f32)
-    h = (h + f32(hf)).astype(f32)
-    h = (h - np.floor(h)).astype(f32)
-    v = maxc
-    h6 = (h * f32(6)).astype(f32)
-    fl = np.floor(h6)
-    f = (h6 - fl).astype(f32)
-    i = fl.astype(np.int32) % 6
-    one = f32(1)
-    p = np.clip(v * (one - s), 0, 1).astype(f32)
-    q = np.clip(v * (one - s * f), 0, 1).astype(f32)
-    t = np.clip(v * (one - s * (one - f)), 0, 1).astype(f32)
-    table = [(v, t, p), (q, v, p), (p, v, t), (p, q, v), (t, p, v), (v, p, q)]
-    out = np.zeros_like(x)
-    for k, (a_, b_, c_) in enumerate(table):
-        m = i == k
+    return np.stack([np.where(eq, 0, uh), np.where(eq, 0, us), maxc], -1).astype(np.uint8)
+
+
+def pil_hsv2rgb(hsv):
+    """Image.convert('RGB') from HSV (libImaging/Convert.c hsv2rgb)."""
+    f64 = np.float64
+    s, v = hsv[..., 1], hsv[..., 2]
+    hh = hsv[..., 0].astype(f32).astype(f64) * 6.0 / 255.0
+    i = np.floor(hh)
+    f = (hh - i.astype(f32).astype(f64)).astype(f32).astype(f64)
+    fs = (s.astype(f32).astype(f64) / 255.0).astype(f32).astype(f64)
+    vf = v.astype(f32).astype(f64)
+    rnd = lambda a: np.clip(np.floor(a + 0.5), 0, 255).astype(np.uint8)          # C round() of a non-negative value, CLIP8
+    p, q, t = rnd(vf * (1.0 - fs)), rnd(vf * (1.0 - fs * f)), rnd(vf * (1.0 - fs * (1.0 - f)))
+    ii = i.astype(np.int32) % 6
+    out = np.zeros(hsv.shape, np.uint8)
+    for k, (a_, b_, c_) in enumerate([(v, t, p), (q, v, p), (p, v, t), (p, q, v), (t, p, v), (v, p, q)]):
+        m = ii == k
         out[..., 0][m], out[..., 1][m], out[..., 2][m] = a_[m], b_[m], c_[m]
+    g = s == 0
+    for c in range(3):
+        out[..., c][g] = v[g]
     return out
+
+
+def hue_shift(hue_factor):
+    """torchvision adjust_hue (PIL path): np_h += np.uint8(hue_factor * 255) with uint8 wrap-around; the cast truncates toward
+    zero and wraps (numpy >= 2 refuses the negative cast outright, the wrap is what the function documents and relies on)."""
+    return int(float(hue_factor) * 255) & 255
+
+
+def pil_hue(x, shift):
+    hsv = pil_rgb2hsv(x)
+    hsv[..., 0] = (hsv[..., 0].astype(np.int32) + int(shift)) & 255
+    return pil_hsv2rgb(hsv)
 
 
 def augment_batch(u8, rows):
@@ -433,25 +513,23 @@ def augment_batch(u8, rows):
     N, H, W, _ = u8.shape
     out = np.zeros((N, 3, H, W), dtype=f32)
     for n in range(N):
-        x = (u8[n].astype(f32) / f32(255)).astype(f32)
+        x = u8[n].copy()
         row = rows[n]
         for k in range(int(row[0])):
             op = int(row[1 + k])
-            fac = row[5 + op]
             if op == 0:
-                x = _blend(x, f32(0), fac)
+                x = pil_brightness(x, row[5])
             elif op == 1:
-                mean = f32(_gray(x).astype(np.float64).mean())
-                x = _blend(x, mean, fac)
+                x = pil_contrast(x, row[6])
             elif op == 2:
-                x = _blend(x, _gray(x)[..., None], fac)
+                x = pil_saturation(x, row[7])
             else:
-                x = _hue(x, fac)
+                x = pil_hue(x, int(row[8]))
         if row[9] != 0:
             x = x[:, ::-1]
-        x = np.array(x, dtype=f32)
+        xf = (x.astype(f32) / f32(255)).astype(f32)           # ToTensor
         for k in range(int(row[10])):
             top, left, h, w = (int(v) for v in row[11 + 4 * k: 15 + 4 * k])
-            x[top:top + h, left:left + w] = 0
-        out[n] = x.transpose(2, 0, 1)
+            xf[top:top + h, left:left + w] = 0
+        out[n] = xf.transpose(2, 0, 1)
     return out

@@ -341,8 +341,66 @@ def gen_data():
     print('G11 data-path fixtures ok')
 
 
+def gen_augment():
+    """G12: the pixel arithmetic of the reference's colour jitter as it really runs -- train.py:32-36 applies RandomColorJitter
+    BEFORE ToTensor, so torchvision's ColorJitter works on the PIL image: PIL.ImageEnhance for brightness / contrast / saturation,
+    and for hue torchvision's PIL path (convert('HSV'), uint8 add on H, convert back; restated here with PIL primitives because
+    torchvision is not installed).  Outputs below are PIL's own; the oracle must reproduce them bit for bit.  Also checks the
+    oracle's two HSV conversions against PIL over ALL 2^24 colours."""
+    from PIL import Image, ImageEnhance
+    import PIL
+    rng_u = synth.uniform(1234, 9, 24 * 20 * 3 + 16)
+    imgs = [(rng_u[:24 * 20 * 3] * 256).astype(np.uint8).reshape(24, 20, 3),
+            np.linspace(0, 255, 16 * 30 * 3).reshape(16, 30, 3).astype(np.uint8)[:, :, ::-1].copy()]
+    imgs[0][:6, :5] = 77                                                  # gray patch: max == min branch of the HSV conversion
+    enh = {0: ImageEnhance.Brightness, 1: ImageEnhance.Contrast, 2: ImageEnhance.Color}
+
+    def pil_apply(arr, ops):
+        im = Image.fromarray(arr, 'RGB')
+        for op, prm in ops:
+            if op < 3:
+                im = enh[op](im).enhance(float(prm))
+            else:                                                          # torchvision.transforms.functional_pil.adjust_hue
+                h, s_, v = im.convert('HSV').split()
+                np_h = np.array(h, dtype=np.uint8)
+                np_h = (np_h.astype(np.int32) + (int(float(prm) * 255) & 255)).astype(np.uint8)   # np_h += np.uint8(hue_factor * 255), wrapping
+                im = Image.merge('HSV', (Image.fromarray(np_h, 'L'), s_, v)).convert('RGB')
+        return np.array(im)
+
+    cases = []
+    for f in (0.0, 0.25, 0.5, 0.77, 1.0, 1.2, 1.5):
+        cases += [[(0, f)], [(1, f)], [(2, f)]]
+    for hf in (-0.5, -0.37, -0.1, 0.0, 0.004, 0.2, 0.37, 0.5):
+        cases.append([(3, hf)])
+    cases += [[(0, 1.3), (1, 0.6), (2, 1.4), (3, 0.37)], [(3, -0.2), (2, 0.5), (1, 1.5), (0, 0.8)], [(1, 0.7), (3, 0.45), (0, 1.1), (2, 1.5)],
+              [(2, 0.9), (0, 0.6), (3, -0.45), (1, 1.25)]]
+    fx = dict(pil_version=np.array(PIL.__version__), n_cases=np.int64(len(cases)))
+    for i, im in enumerate(imgs):
+        fx[f'img_{i}'] = im
+    for ci, ops in enumerate(cases):
+        fx[f'ops_{ci}'] = np.array([[op, prm] for op, prm in ops], dtype=np.float64)
+        for i, im in enumerate(imgs):
+            want = pil_apply(im, ops)
+            x = im.copy()
+            for op, prm in ops:
+                x = (O.pil_brightness, O.pil_contrast, O.pil_saturation)[op](x, prm) if op < 3 else O.pil_hue(x, O.hue_shift(prm))
+            assert np.array_equal(x, want), (ci, i, ops)
+            fx[f'out_{ci}_{i}'] = want
+    # exhaustive: every RGB colour through convert('HSV'), every HSV triple through convert('RGB')
+    a, b, c = np.meshgrid(*[np.arange(256, dtype=np.uint8)] * 3, indexing='ij')
+    cube = np.stack([a, b, c], -1).reshape(4096, 4096, 3)
+    assert np.array_equal(O.pil_rgb2hsv(cube), np.array(Image.fromarray(cube, 'RGB').convert('HSV')))
+    assert np.array_equal(O.pil_hsv2rgb(cube), np.array(Image.fromarray(cube, 'HSV').convert('RGB')))
+    assert np.array_equal(O.pil_luma(cube), np.array(Image.fromarray(cube, 'RGB').convert('L')))
+    fx['exhaustive_hsv_checked'] = np.int64(1)
+    np.savez_compressed(OUT / 'g12_augment_pil.npz', **fx)
+    print(f'G12 augmentation (PIL {PIL.__version__}) fixtures ok: {len(cases)} cases x {len(imgs)} images, HSV conversions exhaustive')
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['post', 'fwd', 'eval', 'data']
+    which = sys.argv[1:] or ['post', 'fwd', 'eval', 'data', 'augment']
+    if 'augment' in which:
+        gen_augment()
     if 'data' in which:
         gen_data()
     if 'eval' in which:

@@ -231,3 +231,119 @@ def test_per_class_nms_option(env, bias, seed):
     assert keep.sum() > keep_agn.sum()
     with pytest.raises(ValueError):
         utils.non_maximum_suppression(torch.from_numpy(pre).to(DEV), variant='lds', per_class=True)
+
+
+def _eval_scene(seed, N, P=8732, G=6, C=21):
+    """Post-decode predictions around seeded ground truth: several jittered copies per GT (rival claimants, some with the wrong
+    class, some too far off), plus unrelated boxes; one positive score column per row like utils.calc_score leaves them."""
+    from object_detection_torch2_amd import synth
+    tg = synth.targets(seed, N, g_max=G, num_classes=C)
+    u = synth.uniform(seed + 1, 5, N * P * 8).reshape(N, P, 8).astype(np.float32)
+    out = np.zeros((N, P, 4 + C), np.float32)
+    for n in range(N):
+        live = np.nonzero(tg[n, :, 2] > 0)[0]
+        # two GT boxes of one class close together in image 0: both claimed by the same predictions
+        if n == 0 and len(live) >= 2:
+            tg[n, live[1]] = tg[n, live[0]]
+            tg[n, live[1], 0] += 0.02
+        for p in range(P):
+            if len(live) and u[n, p, 0] < 0.03:                       # a claimant of GT g
+                g = live[int(u[n, p, 1] * len(live)) % len(live)]
+                jit = (u[n, p, 2:6] - 0.5) * (0.5 if u[n, p, 6] < 0.3 else 0.12)
+                out[n, p, :4] = tg[n, g, :4] * (1 + jit)
+                cls = int(np.argmax(tg[n, g, 4:])) if u[n, p, 7] < 0.8 else 1 + int(u[n, p, 7] * 1000) % (C - 1)
+            elif u[n, p, 0] < 0.05:
+                out[n, p, :4] = [u[n, p, 1], u[n, p, 2], 0.05 + 0.3 * u[n, p, 3], 0.05 + 0.3 * u[n, p, 4]]
+                cls = 1 + int(u[n, p, 5] * 1000) % (C - 1)
+            else:
+                continue
+            out[n, p, 4 + cls] = 0.05 + 0.9 * u[n, p, 6] * u[n, p, 7] + 1e-4 * (p % 97)
+    return out, tg
+
+
+@pytest.mark.parametrize('N,G', [(1, 3), (4, 6), (3, 1)])
+def test_eval_true_positive_assignment_vs_oracle(N, G):
+    """8(f)-1: evaluate.py:128-151 on REAL NMS output: the device pass (`ssdhip_eval_match` through evaluate.match_true_positives)
+    against the oracle's restatement of the reference loop -- same rows per class, same TP flags, same scores, same GT counts;
+    then AP of both in the reference's definition and the score-ranked one."""
+    from oracle import ssd_oracle as O
+    from object_detection_torch2_amd import evaluate as E, utils
+    out, tg = _eval_scene(900 + 10 * N + G, N, G=G)
+    t = torch.from_numpy(out.copy()).to(DEV)
+    utils.non_maximum_suppression(t)
+    post = t.cpu().numpy()
+    gt_count = torch.zeros(20, dtype=torch.int32, device=DEV)
+    cls, tp, score = (x.cpu().numpy() for x in E.match_true_positives(t, torch.from_numpy(tg).to(DEV), 0.5, gt_count))
+    want_count = np.zeros(20, np.int64)
+    n_tp = n_rows = 0
+    for n in range(N):
+        rows, counts = O.eval_image(post[n], tg[n])
+        for c in range(20):
+            want_count[c] += counts[c]
+            sel = np.nonzero(cls[n] == c)[0]
+            sel = sel[np.argsort(-score[n, sel], kind='stable')]
+            if c not in rows:
+                assert len(sel) == 0, (n, c)
+                continue
+            assert len(sel) == len(rows[c]), (n, c)
+            assert np.array_equal(score[n, sel], rows[c][:, 1]), (n, c)
+            assert np.array_equal(tp[n, sel].astype(np.float32), rows[c][:, 0]), (n, c)
+            n_tp += int(rows[c][:, 0].sum()); n_rows += len(sel)
+        # void / suppressed rows carry no class
+        assert np.array_equal(cls[n] < 0, ~(post[n][:, 5:] > 0).any(axis=1))
+    assert np.array_equal(gt_count.cpu().numpy(), want_count)
+    assert n_rows > 20 and n_tp < n_rows                        # false positives everywhere ...
+    assert N < 3 or n_tp > 0                                    # ... and true positives once there are a few images (class-agnostic NMS
+    #                                                             leaves one survivor per ground-truth neighbourhood: right class 4 times in 5)
+
+
+def test_evaluate_batches_ap_vs_oracle():
+    """The accumulated per-class tables of evaluate.evaluate_batches (what the AP is computed from) against the oracle loop over the
+    same post-processed outputs, through a stand-in `net` that returns prepared logits (decode and NMS are the real HIP ones)."""
+    from oracle import ssd_oracle as O
+    from object_detection_torch2_amd import evaluate as E, utils
+    df = O.default_bboxes()
+    scenes = [_eval_scene(950 + b, 2, G=5) for b in range(2)]
+    # logits whose decode gives the scene's boxes and whose softmax arg-max is the scene's class
+    def logits(out):
+        lg = np.zeros_like(out)
+        lg[:, :, 0] = (out[:, :, 0] - df[None, :, 0]) / df[None, :, 2]
+        lg[:, :, 1] = (out[:, :, 1] - df[None, :, 1]) / df[None, :, 3]
+        lg[:, :, 2] = np.log(np.maximum(out[:, :, 2], 1e-6) / df[None, :, 2])
+        lg[:, :, 3] = np.log(np.maximum(out[:, :, 3], 1e-6) / df[None, :, 3])
+        has = (out[:, :, 4:] > 0).any(axis=2)
+        lg[:, :, 4] = np.where(has, 0.0, 8.0)                               # rows without a box: void wins
+        lg[:, :, 4:] += np.where(out[:, :, 4:] > 0, 4.0 + 4.0 * out[:, :, 4:], 0.0)
+        return lg.astype(np.float32)
+    batches = [(torch.from_numpy(logits(o)).to(DEV), torch.from_numpy(g).to(DEV)) for o, g in scenes]
+
+    class Stub:
+        def __call__(self, x):
+            return x.clone()
+    correct, count = E.evaluate_batches(Stub(), torch.from_numpy(df).to(DEV), batches)
+    want_rows = {c: [] for c in range(20)}
+    want_count = {c: 0 for c in range(20)}
+    for lg, g in batches:
+        o = lg.clone()
+        utils.decode_score_(o, torch.from_numpy(df).to(DEV))
+        utils.non_maximum_suppression(o)
+        for n in range(o.shape[0]):
+            rows, counts = O.eval_image(o[n].cpu().numpy(), g[n].cpu().numpy())
+            for c in range(20):
+                want_count[c] += counts[c]
+                if c in rows:
+                    want_rows[c].append(rows[c])
+    assert count == want_count
+    n_ap = 0
+    for c in range(20):
+        assert len(correct[c]) == len(want_rows[c]), c
+        if not want_rows[c] or want_count[c] == 0:
+            continue
+        got, want = torch.cat(correct[c]).numpy(), np.concatenate(want_rows[c])
+        assert np.array_equal(got, want), c
+        for mode in (True, False):
+            a = E.calc_average_precision(torch.from_numpy(got), count[c], mode).item()
+            b = E.calc_average_precision(torch.from_numpy(want), want_count[c], mode).item()
+            assert a == b and 0.0 <= a <= 1.0
+        n_ap += 1
+    assert n_ap >= 3

@@ -133,6 +133,23 @@ def test_average_precision_matches_reference_and_voc(golden):
     # TP assignment: two predictions claim GT 0, only the first (higher score) is a TP; the third matches nothing
     iou = torch.tensor([[0.9, 0.1], [0.8, 0.2], [0.3, 0.4]])
     assert E.assign_true_positives(iou).view(-1).tolist() == [1.0, 0.0, 0.0]
+    # the oracle's restatement of the evaluation loop (evaluate.py:31-42, 134-151) agrees with the reference-pinned pieces
+    assert np.array_equal(O.get_order(t.numpy(), 4), fx['order_c4'])
+    out = np.zeros((5, 25), np.float32); gt = np.zeros((3, 25), np.float32)
+    gt[0, :4] = [0.5, 0.5, 0.2, 0.2]; gt[0, 5 + 2] = 1          # class 2
+    gt[1, :4] = [0.2, 0.2, 0.1, 0.1]; gt[1, 5 + 7] = 1          # class 7, nobody claims it
+    out[0, :4] = [0.5, 0.5, 0.2, 0.2]; out[0, 5 + 2] = 0.6       # exact hit, but lower score than row 3
+    out[3, :4] = [0.51, 0.5, 0.2, 0.2]; out[3, 5 + 2] = 0.9      # first claimant of GT 0 -> TP
+    out[1, :4] = [0.9, 0.9, 0.1, 0.1]; out[1, 5 + 2] = 0.8       # class 2, far away -> FP
+    out[2, :4] = [0.5, 0.5, 0.2, 0.2]; out[2, 5 + 3] = 0.7       # right place, wrong class, no GT of class 3 -> FP
+    rows, counts = O.eval_image(out, gt)
+    assert counts[2] == 1 and counts[7] == 1 and counts[3] == 0 and sorted(rows) == [2, 3]
+    assert rows[2].tolist() == [[1.0, np.float32(0.9)], [0.0, np.float32(0.8)], [0.0, np.float32(0.6)]]
+    assert rows[3].tolist() == [[0.0, np.float32(0.7)]]
+    # ... and with the torch form of the same expression used by the host module
+    iou2 = torch.from_numpy(O.calc_iou(out[None], gt[None])[0])
+    po, go = E.get_order(torch.from_numpy(out), 2), E.get_order(torch.from_numpy(gt), 2)
+    assert E.assign_true_positives(iou2[po][:, go]).view(-1).tolist() == rows[2][:, 0].tolist()
 
 
 def test_plain_c_program_links_against_the_library(tmp_path):
