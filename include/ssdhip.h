@@ -232,14 +232,15 @@ int ssdhip_conv_c64(const float* x, const float* wimg, const float* bias, const 
  * of ssdhip_wino_fused_weight_floats(Cout, Cin) floats; in_scale/in_shift (Cin) or both NULL; z (N,H,W,Cout);
  * stats NULL or (ssdhip_wino_fused_stat_rows(N,H,W), Cout, 2); geo = tile-block geometry of the map shape, filled once per
  * (N,H,W) by ssdhip_wino_fused_geo into ssdhip_wino_fused_geo_bytes(N,H,W) bytes (caller-owned, reusable by every layer and
- * step of that shape).  ssdhip_wino_fused_conv returns the number of stats rows (>= 0) or a negative code.                   */
+ * step of that shape).  max_blocks: 0 = one block per CU (256); a smaller grid leaves whole CUs to kernels running on other
+ * streams.  ssdhip_wino_fused_conv returns the number of stats rows (>= 0) or a negative code.                               */
 int64_t ssdhip_wino_fused_weight_floats(int Cout, int Cin);
 int ssdhip_wino_fused_pack(const float* w_oihw, float* upk, int Cout, int Cin, void* stream);
 int ssdhip_wino_fused_stat_rows(int N, int H, int W);
 int64_t ssdhip_wino_fused_geo_bytes(int N, int H, int W);
 int ssdhip_wino_fused_geo(int N, int H, int W, void* geo, void* stream);
 int ssdhip_wino_fused_conv(const float* x, const float* upk, const float* bias, const float* in_scale, const float* in_shift, float* z,
-                           float* stats, const void* geo, int N, int H, int W, int Cin, int Cout, void* stream);
+                           float* stats, const void* geo, int N, int H, int W, int Cin, int Cout, int max_blocks, void* stream);
 
 /* ---- 8(f)-4  full fine-tuning (train.py:69-74 un-freezes nothing; extension): backward of MaxPool2d(2,2,pad) over the
  * recomputed a = relu(z*scale+shift) (vgg16.py:28-35): dpooled (N,Ho,Wo,C) -> da (N,H,W,C), gradient to the first maximum

@@ -93,7 +93,7 @@ SIGNATURES = {
     'ssdhip_wino_fused_geo_bytes': (c_int64, [c_int, c_int, c_int]),
     'ssdhip_wino_fused_geo': (c_int, [c_int, c_int, c_int, c_void_p, c_void_p]),
     'ssdhip_wino_fused_conv': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                       c_int, c_int, c_void_p]),
+                                       c_int, c_int, c_int, c_void_p]),
     'ssdhip_bn_relu_pool_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ssdhip_augment_row_floats': (c_int, []),
     'ssdhip_augment_ws_bytes': (c_int64, [c_int]),

@@ -162,9 +162,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int wm = wave >> 1, wn = wave & 1;
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)lds;
     // work items id = blockIdx.x + j * gridDim.x; the host makes gridDim.x a multiple of NB, so the channel tile is fixed per block
-    const int G = gridDim.x, items = a.MB * a.NB;
-    const int cnt = (items - (int)blockIdx.x + G - 1) / G;
-    const int nb = blockIdx.x % a.NB, mb0 = blockIdx.x / a.NB, mbstep = G / a.NB;
+    // The grid is a multiple of NB (host), so a block keeps its channel tile nb and walks tile blocks mb0, mb0 + mbstep, ...
+    // Which blocks share a tile block is a speed matter only: with the round-robin XCD placement (block b on XCD b % 8) the NB
+    // blocks of one tile block are given ids that differ by 8, i.e. one XCD, so the input strips they all fetch at the same time
+    // miss that XCD's L2 once instead of NB times (measured fabric traffic was 3x the algorithmic bytes without it).
+    const int G = gridDim.x, mbstep = G / a.NB;
+    int nb, mb0;
+    if (G % (8 * a.NB) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        nb = slot % a.NB;
+        mb0 = (slot / a.NB) * 8 + xcd;
+    } else {
+        nb = blockIdx.x % a.NB;
+        mb0 = blockIdx.x / a.NB;
+    }
+    if (mb0 >= a.MB) return;                 // fewer tile blocks than groups (whole block: uniform)
+    const int cnt = (a.MB - mb0 + mbstep - 1) / mbstep;
     const int n0 = nb * WF_COUT;
     const int KT = (ABL & 16) ? 4 : a.KT;
 
@@ -474,8 +487,8 @@ int ssdhip_wino_fused_geo(int N, int H, int W, void* geo, void* stream) {
 }
 
 int ssdhip_wino_fused_conv(const float* x, const float* upk, const float* bias, const float* in_scale, const float* in_shift, float* z,
-                           float* stats, const void* geo, int N, int H, int W, int Cin, int Cout, void* stream) {
-    SSDHIP_REQUIRE(x && upk && z && geo && N > 0 && H > 0 && W > 0, "wino_fused_conv: bad arguments");
+                           float* stats, const void* geo, int N, int H, int W, int Cin, int Cout, int max_blocks, void* stream) {
+    SSDHIP_REQUIRE(x && upk && z && geo && N > 0 && H > 0 && W > 0 && max_blocks >= 0, "wino_fused_conv: bad arguments");
     SSDHIP_REQUIRE(Cin >= 32 && Cin % 16 == 0 && Cin <= WF_MAXC && Cout > 0 && Cout % WF_COUT == 0,
                    "wino_fused_conv: Cin must be a multiple of 16 in 32..512 and Cout a multiple of 64");
     SSDHIP_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "wino_fused_conv: in_scale and in_shift go together");
@@ -505,7 +518,9 @@ int ssdhip_wino_fused_conv(const float* x, const float* upk, const float* bias, 
     a.x_bytes = (unsigned)((int64_t)N * H * W * Cin * 4);
     // persistent grid: one block per CU, a multiple of NB so that a block keeps its channel tile (and its weight slice in L2)
     const int64_t items = (int64_t)a.MB * a.NB;
-    int G = items < 256 ? (int)items : 256 / a.NB * a.NB;
+    // (max_blocks > 0 leaves CUs to kernels of other streams: a block fills its CU's LDS and registers for the whole launch)
+    const int cap = max_blocks > 0 && max_blocks < 256 ? (max_blocks < a.NB ? a.NB : max_blocks) : 256;
+    int G = items < cap ? (int)items : cap / a.NB * a.NB;
     dim3 grid((unsigned)G), block(256);
     hipStream_t st = (hipStream_t)stream;
 #ifdef SSDHIP_PROBES

@@ -98,6 +98,9 @@ class Engine:
                                # backbone pass: the forward consumers (det_4_3 head, conv_6_1) and their weight gradients
         self.bf16 = False      # set per forward from module.compute_dtype; backward follows the saved forward
         self.prof = None       # list: when set, forward conv launches are bracketed by events (bench.py roofline leg)
+        # grid of the persistent fused Winograd kernel: 0 = one block per CU; a block fills its CU (LDS, registers) for the whole
+        # launch, so a smaller grid leaves CUs to the tail / weight-gradient streams that run beside the backbone
+        self._wf_blocks = int(os.environ.get('SSD_WF_BLOCKS', '0'))
 
     # ------------------------------------------------------------------------------------------------ helpers
     def _weight(self, spec):
@@ -350,7 +353,10 @@ class Engine:
     def _side_stream(self, dev, which=0):
         st = self._side.get((dev, which))
         if st is None:
-            st = torch.cuda.Stream(device=dev)
+            # the frozen backbone (which = 2) fills the chip with long launches; the side stream's short, dependent launches (heads,
+            # weight gradients, repacking) go first whenever both have work ready (SSD_STREAM_PRIO=0 disables)
+            prio = -1 if (which != 2 and os.environ.get('SSD_STREAM_PRIO', '1') == '1') else 0
+            st = torch.cuda.Stream(device=dev, priority=prio)
             self._side[(dev, which)] = st
         return st
 
@@ -464,12 +470,22 @@ class Engine:
                     if c.wf_key != key:
                         _lib.check(self.lib.ssdhip_wino_fused_pack(_lib.ptr(w1), _lib.ptr(c.wf_img), c.cout, c.cin, st), f'wino_fused_pack {c.name}')
                         c.wf_key = key
+                    if self.prof is not None:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
                     rows = _lib.check(self.lib.ssdhip_wino_fused_conv(_lib.ptr(cur), _lib.ptr(c.wf_img), _lib.ptr(b1) if b1 is not None else None,
                                                                       _lib.ptr(cur_xs[0]) if cur_xs is not None else None,
                                                                       _lib.ptr(cur_xs[1]) if cur_xs is not None else None, _lib.ptr(z),
                                                                       _lib.ptr(ws['partial']) if training else None,
                                                                       _lib.ptr(self._wf_geo(b, N, g['hi'], g['wi'], dev)), N, g['hi'], g['wi'],
-                                                                      c.cin, c.cout, st), f'conv2d {c.name}')
+                                                                      c.cin, c.cout, self._wf_blocks, st), f'conv2d {c.name}')
+                    if self.prof is not None:
+                        e1.record()
+                        tiles = N * ((g['hi'] + 1) // 2) * ((g['wi'] + 1) // 2)
+                        self.prof.append(dict(layer=c.name + ' (fused Winograd)', e0=e0, e1=e1,
+                                              kernel='wino_fused_kernel<%s, 0>' % ('true' if cur_xs is not None else 'false'),
+                                              flops=2.0 * 16 * tiles * c.cin * c.cout,            # MFMA flops of the 16 Winograd-domain products
+                                              direct_flops=2.0 * N * g['hi'] * g['wi'] * c.cin * c.cout * 9))
                 elif c.wino and self._wino_ok(g) and not self.bf16:     # bf16 MFMA outruns the fp32 Winograd pipeline: direct kernel
                     rows = self._conv_winograd(c, cur, cur_xs, z, ws, N, g['hi'], g['wi'], ws['partial'] if training else None)
                 elif (c.cin == 64 and c.cout in (64, 128) and c.k == 3 and c.stride == 1 and c.pad == 1 and min(g['hi'], g['wi']) >= 100

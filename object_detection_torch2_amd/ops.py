@@ -122,7 +122,7 @@ def wino_fused_geo(N, H, W, device):
     return g
 
 
-def wino_fused_conv(x, w_oihw, bias=None, in_scale=None, in_shift=None, want_stats=False, upk=None):
+def wino_fused_conv(x, w_oihw, bias=None, in_scale=None, in_shift=None, want_stats=False, upk=None, max_blocks=0):
     """3x3/s1/p1 conv as ONE fused Winograd F(2x2,3x3) kernel: x (N,H,W,Cin) NHWC -> (z (N,H,W,Cout), stats (MB,Cout,2) or None)."""
     _lib.require_gpu(x, w_oihw)
     lib = _lib.load()
@@ -139,7 +139,7 @@ def wino_fused_conv(x, w_oihw, bias=None, in_scale=None, in_shift=None, want_sta
                                           _lib.ptr(in_scale) if in_scale is not None else None,
                                           _lib.ptr(in_shift) if in_shift is not None else None, _lib.ptr(z),
                                           _lib.ptr(stats) if stats is not None else None, _lib.ptr(wino_fused_geo(N, H, W, x.device)),
-                                          N, H, W, C, cout, _lib.stream()), 'wino_fused_conv')
+                                          N, H, W, C, cout, max_blocks, _lib.stream()), 'wino_fused_conv')
     return z, stats
 
 

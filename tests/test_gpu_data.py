@@ -142,3 +142,14 @@ def test_evaluate_and_inference_entry_points(tmp_path, monkeypatch, capsys):
     monkeypatch.setattr(sys, 'argv', ['inference', '--batch_size', '2', '--result_dir', str(tmp_path / 'result')])
     inference.main()
     assert 'Finished' in capsys.readouterr().out
+    # inference.py:25-69 over the dataset (PascalVOCDataset + ToTensor + collate_fn), annotated images like inference.py:101
+    monkeypatch.setattr(sys, 'argv', ['inference', '--data_dirs', str(root), '--batch_size', '2', '--num_workers', '0', '--save_png',
+                                      '--result_dir', str(tmp_path / 'result')])
+    inference.main()
+    out = capsys.readouterr().out
+    n_images = len((root / 'ImageSets' / 'Main' / 'test.txt').read_text().split())
+    assert out.count('detections, top:') == n_images and 'Finished Inference' in out
+    pngs = sorted((tmp_path / 'result' / 'detection').glob('0*.png'))
+    assert len(pngs) == n_images
+    from PIL import Image
+    assert Image.open(pngs[0]).size == (300, 300)
