@@ -93,3 +93,47 @@ def test_large_prior_set_nms_keep_set_exact(env, P, bias, seed):
     assert got.sum() == want.sum() and np.array_equal(got, want)
     post = t.cpu().numpy()[0]
     assert np.array_equal(post[:, :4], pre[0, :, :4]) and np.all(post[~got, 4:] == 0) and np.array_equal(post[got, 4:], pre[0][got, 4:])
+
+
+def test_ssd512_bf16_forward_and_step(env):
+    """BASELINE configs[4] in its single-GPU form: SSD512 in bf16 compute mode (bf16 MFMA operands, fp32 accumulate, fp32 master
+    state) -- forward and one train step against the oracle's fp32 run of the same network.  Tolerances = the SSD300 bf16 test's
+    (bf16 operands cost 2^-9 per product, amplified ~16x by the random-init network): 5 % relative L2 on the 64x64 head, 10 % over all
+    priors, loss within 2 %, detector weight gradients within 10 % and pointing the same way."""
+    from object_detection_torch2_amd.model import SSD
+    from object_detection_torch2_amd.optim import FusedAdam
+    O, synth = env['O'], env['synth']
+    sd = O.init_state(seed=1, imsize=512)
+    names = O.trainable_param_names(imsize=512)
+    ims, tg, df = synth.images(61, 2, 512), synth.targets(62, 2, g_max=8), O.default_bboxes(512)
+    for k in names:
+        sd[k].requires_grad_(True)
+    out_o = O.forward(sd, torch.from_numpy(ims), training=True, imsize=512)
+    o = out_o.detach().numpy()
+    out_o.backward(torch.from_numpy(O.loss_grad(o, tg, df)))
+    net = SSD(num_classes=21, imsize=512)
+    net.load_state_dict(O.init_state(seed=1, imsize=512))
+    net.to(DEV).set_compute_dtype('bf16')
+    opt = FusedAdam(net.train_params(), lr=1e-3, weight_decay=5e-4)
+    opt.zero_grad()
+    out = net(torch.from_numpy(ims).to(DEV))
+    assert tuple(out.shape) == (2, 24564, 25) and torch.isfinite(out).all()
+    d = out.detach().cpu().numpy() - o
+    n_head = 64 * 64 * 4
+    assert np.linalg.norm(d) / np.linalg.norm(o) < 0.10
+    assert np.linalg.norm(d[:, :n_head]) / np.linalg.norm(o[:, :n_head]) < 0.05
+    loss = net.loss(out, torch.from_numpy(tg).to(DEV), torch.from_numpy(df).to(DEV))
+    ref = float(O.loss(o, tg, df))
+    assert abs(loss.item() - ref) < 0.02 * abs(ref), (loss.item(), ref)
+    loss.backward()
+    got = dict(net.named_train_params())
+    for k in names:
+        if not (k.startswith('detectors.') and k.endswith('.weight')):
+            continue
+        g, r = got[k].grad.cpu().double(), sd[k].grad.double()
+        rel = ((g - r).norm() / r.norm()).item()
+        cos = (g * r).sum().item() / (g.norm().item() * r.norm().item())
+        assert rel < 0.10 and cos > 0.995, (k, rel, cos)
+    before = net.detectors['det_4_3'].weight.detach().clone()
+    opt.step()
+    assert not torch.equal(before, net.detectors['det_4_3'].weight) and net.detectors['det_4_3'].weight.dtype == torch.float32
