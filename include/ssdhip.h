@@ -248,6 +248,19 @@ int ssdhip_wino_fused_conv(const float* x, const float* upk, const float* bias, 
 int ssdhip_bn_relu_pool_bwd(const float* z, const float* scale, const float* shift, const float* dpooled, float* da, int N, int H, int W,
                             int C, int pool_pad, void* stream);
 
+/* ---- 8(f)-4  VGG16 classification head (model/vgg16.py:42-61, 96-101, 117-130).  The Linear layers run on ssdhip_conv2d_nhwc /
+ * ssdhip_conv2d_wgrad as 1x1 convolutions; these are the element-wise pieces.
+ * nhwc_flatten: (N,H,W,C) NHWC <-> the reference's x.view(N,-1) of NCHW (index c*H*W + h*W + w); inverse != 0 goes back.
+ * relu_dropout: out = relu(x) * mask / (1-p) (dy == NULL) or dy * that mask (backward); mask[i] = 24-bit counter hash(key, i) >= p
+ *   (synth.hash_u32); training == 0: plain ReLU.  n < 2^32.
+ * log_softmax_dot: loss[0] = sign * mean_n sum_c t[n][c] * log_softmax(z[n])[c] (rowval: N floats scratch);
+ *   bwd: dlogits = grad_out[0] * sign / N * (t - softmax(z) * sum_c t)  (scratch1: 1 float).  sign = +1: vgg16.py:127-129 literally. */
+int ssdhip_nhwc_flatten(const float* src, float* dst, int N, int H, int W, int C, int inverse, void* stream);
+int ssdhip_relu_dropout(const float* x, const float* dy, float* out, int64_t n, float p, uint32_t key, int training, void* stream);
+int ssdhip_log_softmax_dot_fwd(const float* logits, const float* targets, int N, int C, float sign, float* rowval, float* loss, void* stream);
+int ssdhip_log_softmax_dot_bwd(const float* logits, const float* targets, int N, int C, float sign, const float* grad_out, float* scratch1,
+                               float* dlogits, void* stream);
+
 /* ---- 8(f)-2  batch augmentation (augmentation/random.py:6-42, augmentation/to_tensor.py:8-16, applied per sample at
  * dataset.py:43-52; pipeline train.py:32-36): colour jitter ops in the sampled order, horizontal flip, uint8 -> [0,1]
  * fp32 (ToTensor) and up to three erased boxes, on the whole batch.

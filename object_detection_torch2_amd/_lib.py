@@ -95,6 +95,10 @@ SIGNATURES = {
     'ssdhip_wino_fused_conv': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                        c_int, c_int, c_int, c_void_p]),
     'ssdhip_bn_relu_pool_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'ssdhip_nhwc_flatten': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'ssdhip_relu_dropout': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, ctypes.c_uint32, c_int, c_void_p]),
+    'ssdhip_log_softmax_dot_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    'ssdhip_log_softmax_dot_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'ssdhip_augment_row_floats': (c_int, []),
     'ssdhip_augment_ws_bytes': (c_int64, [c_int]),
     'ssdhip_augment_batch': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -118,7 +118,8 @@ class RandomFlip:
         img = _deferred(img)
         if torch.rand(1) < self.p:
             img.row[9] = 1.0 - img.row[9]
-            gt[:, 0] = 1 - gt[:, 0]
+            if gt.dim() == 2:                   # detection rows [cx, cy, ...]; a classification target (one-hot vector) has no geometry
+                gt[:, 0] = 1 - gt[:, 0]        # (the reference indexes gt[:, 0] unconditionally and fails on it: random.py:31)
         return img, gt
 
 

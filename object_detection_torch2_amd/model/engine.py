@@ -65,6 +65,9 @@ class Engine:
         self.lib = _lib.load()
         self.nc = module.num_classes
         self.row = self.nc + 4
+        # name -> layer module: SSD keeps the reference's ModuleDicts; the VGG16 classifier keeps the reference's nn.Sequential
+        # (state_dict keys features.<index>.*) and hands out a name lookup
+        self._feat = module.feature_lookup() if hasattr(module, 'feature_lookup') else module.features
         plan = T.feature_plan(module.topo)
         heads = {h['tag']: (i, h) for i, h in enumerate(T.head_plan(self.nc, module.topo))}
         self.stages = []
@@ -85,7 +88,8 @@ class Engine:
                 head = _ConvSpec(h['name'], h['cin'], h['cout'], 3, 1, 1, False, is_head=True)
                 head.anchors = h['anchors']
             self.stages.append(_Stage(conv, bn, pool_pad, head, hidx))
-        self.tail_start = next(i for i, s in enumerate(self.stages) if not s.conv.frozen)
+        self.tail_start = next((i for i, s in enumerate(self.stages) if not s.conv.frozen), len(self.stages))
+        self.headless = not any(s.head is not None for s in self.stages)      # VGG16 classifier: forward returns the last activation
         self._bufs = {}
         self._bn = {}          # bn name -> dict(scale, shift, mean, invstd)
         self._saved = None     # forward context consumed by backward
@@ -104,7 +108,7 @@ class Engine:
 
     # ------------------------------------------------------------------------------------------------ helpers
     def _weight(self, spec):
-        mod = (self.m.detectors if spec.is_head else self.m.features)[spec.name]
+        mod = (self.m.detectors if spec.is_head else self._feat)[spec.name]
         return mod.weight, mod.bias
 
     def _pack(self, spec, dgrad=False):
@@ -442,7 +446,7 @@ class Engine:
         cur, cur_xs = b['x4'], None
         for i, (s, g) in enumerate(zip(self.stages, geo)):
             c = s.conv
-            bnm = self.m.features[s.bn_name]
+            bnm = self._feat[s.bn_name]
             on_bb = bb is not None and i < self.tail_start
             if i == self.tail_start:
                 if bb is not None:
@@ -556,10 +560,16 @@ class Engine:
                                        g['ho'], g['wo'], None)
                     if on_bb:
                         self._note_reader(i, fork.mark())
+        if bb is not None and self.tail_start >= len(self.stages):
+            main.wait_event(bb.record_event())       # everything frozen (VGG16 transfer learning): the whole stack ran on the backbone stream
         fork.join()
         if nbt:
             torch._foreach_add_(nbt, 1)
         self._saved = dict(b=b, N=N, acts=acts, training=training, bf16=self.bf16) if save else None
+        if self.headless:
+            if cur_xs is not None:
+                raise RuntimeError('a head-less feature stack must end in a pool (its BN.ReLU is applied there)')
+            return cur          # (N, h, w, C) NHWC: the pooled last activation (a workspace tensor: consume it before the next forward)
         return out
 
     # ------------------------------------------------------------------------------------------------ backward
@@ -723,6 +733,16 @@ class Engine:
                 _lib.check(L.ssdhip_scatter_head_grad(_lib.ptr(grad_out), _lib.ptr(bw['dyh'][i]), N, b['P'], self.row,
                                                       b['head_off'][s.head_index], g['ho'] * g['wo'], s.head.cout, s.head.co_pad, st),
                            'scatter_head_grad')
+        if self.headless:
+            # grad_out = gradient of the pooled last activation (N, ha, wa, C) NHWC: through BN.ReLU.MaxPool into da[last]
+            last_i = len(self.stages) - 1
+            ls, lg = self.stages[last_i], geo[last_i]
+            lst = self._bn[ls.bn_name]
+            if tuple(grad_out.shape) != (N, lg['ha'], lg['wa'], ls.conv.cout):
+                raise ValueError(f'backward: expected a gradient of shape {(N, lg["ha"], lg["wa"], ls.conv.cout)}, got {tuple(grad_out.shape)}')
+            _lib.check(L.ssdhip_bn_relu_pool_bwd(_lib.ptr(b['z'][last_i]), _lib.ptr(lst['scale']), _lib.ptr(lst['shift']), _lib.ptr(grad_out),
+                                                 _lib.ptr(bw['da'][last_i]), N, lg['ho'], lg['wo'], ls.conv.cout, ls.pool_pad, st),
+                       f'pool backward after {ls.conv.name}')
         # Weight gradients are leaves of the dependency graph (nothing downstream reads them before the optimizer): they all go
         # to the side stream, each after the main stream has produced its dy, and run next to the BN / data-gradient chain.
         fork = self._Fork(self, dev)

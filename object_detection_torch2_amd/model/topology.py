@@ -20,9 +20,10 @@ class Topology:
     the 300-px grid, ssd.py:118): BASELINE configs[4]'s 24,564-prior layout = maps 64/32/16/8/4/2/1 with 4/6/6/6/6/4/4
     anchors, which needs pool_3 without padding on the even 128-px map and five stride-2 extras (one extra stage)."""
 
-    def __init__(self, imsize, vgg_cfg, extra_cfg, head_cfg, box_maps, s_min=S_MIN, s_max=S_MAX):
+    def __init__(self, imsize, vgg_cfg, extra_cfg, head_cfg, box_maps, s_min=S_MIN, s_max=S_MAX, keep_pool5=False, vgg_frozen=True):
         self.imsize, self.vgg_cfg, self.extra_cfg, self.head_cfg, self.box_maps = imsize, vgg_cfg, extra_cfg, head_cfg, box_maps
         self.s_min, self.s_max = s_min, s_max
+        self.keep_pool5, self.vgg_frozen = keep_pool5, vgg_frozen
 
     def num_priors(self):
         return sum(m * n * a for m, n, a in self.box_maps)
@@ -38,6 +39,12 @@ SSD512 = Topology(
     ((64, 64, 4), (32, 32, 6), (16, 16, 6), (8, 8, 6), (4, 4, 6), (2, 2, 4), (1, 1, 4)))
 
 
+# the VGG16-bn classifier's feature stack (model/vgg16.py:22-39): every layer of the cfg incl. the last pool, nothing frozen, no
+# extras / heads / default boxes; any input size (the classifier needs a 7x7 final map: 184..215 px with these pools)
+VGG16_FEATURES = Topology(None, VGG_CFG, (), (), (), keep_pool5=True, vgg_frozen=False)
+VGG16_FEATURES_FROZEN = Topology(None, VGG_CFG, (), (), (), keep_pool5=True, vgg_frozen=True)      # transfer_learning=True (vgg16.py:72-75)
+
+
 def topology_for(imsize):
     if imsize == 300:
         return SSD300
@@ -48,17 +55,17 @@ def topology_for(imsize):
 
 def feature_plan(topo=SSD300):
     """Ordered list of feature layers.  conv: name,cin,cout,k,stride,pad,frozen; bn: name,c,frozen; act; pool: name,pad.
-    pool_5 is dropped and every VGG layer is frozen (ssd.py:31-41)."""
+    SSD: pool_5 is dropped and every VGG layer is frozen (ssd.py:31-41); the VGG16 classifier keeps pool_5 and trains everything."""
     plan, cin, stage, sub = [], 3, 1, 1
     for v in topo.vgg_cfg:
         if isinstance(v, str):
-            if stage < 5:
+            if stage < 5 or topo.keep_pool5:
                 plan.append(dict(kind='pool', name=f'pool_{stage}', pad=1 if v == 'M_P' else 0))
             stage, sub = stage + 1, 1
             continue
         tag = f'{stage}_{sub}'
-        plan.append(dict(kind='conv', name=f'conv_{tag}', tag=tag, cin=cin, cout=v, k=3, stride=1, pad=1, frozen=True))
-        plan.append(dict(kind='bn', name=f'bn_{tag}', tag=tag, c=v, frozen=True))
+        plan.append(dict(kind='conv', name=f'conv_{tag}', tag=tag, cin=cin, cout=v, k=3, stride=1, pad=1, frozen=topo.vgg_frozen))
+        plan.append(dict(kind='bn', name=f'bn_{tag}', tag=tag, c=v, frozen=topo.vgg_frozen))
         plan.append(dict(kind='act', name=f'act_{tag}', tag=tag))
         cin, sub = v, sub + 1
     for group in topo.extra_cfg:

@@ -70,8 +70,9 @@ def main():
     parser.add_argument('--data_dirs', type=str, nargs='*', default=None, help='VOC roots, e.g. /work/data/VOCdevkit/VOC2007 (train.py:43)')
     parser.add_argument('--data_list', type=str, default='trainval.txt')
     args = parser.parse_args()
-    if args.purpose != 'detection':
-        raise SystemExit('only --purpose detection is on the MI355X path (VGG16 classification pre-training is out of scope)')
+    if args.purpose not in ('detection', 'classification'):
+        raise SystemExit(f'--purpose must be detection or classification, got {args.purpose!r}')
+    classify = args.purpose == 'classification'
 
     rank, world, local = parallel.init_from_env()
     device = torch.device('cuda', local)
@@ -79,8 +80,18 @@ def main():
     weights_path = Path(args.result_dir) / args.purpose / args.weights
     params_path = Path(args.result_dir) / args.purpose / args.params
 
-    net = build_model(device, world, weights_path, Path(args.result_dir) / 'classification' / args.weights)
-    defaults = net.default_bboxes.to(device)
+    if classify:
+        # train.py:69-74.  The reference cannot run this branch (VGG16 has no train_params(), its loss has the wrong sign, its
+        # Linear(512*7*7) does not fit the default --imsize 300: DESIGN.md); here it trains: NLL loss, --imsize 184..215.
+        from .model import VGG16
+        net = VGG16(num_classes=20, weights_path=weights_path, transfer_learning=True).unfreeze_features()   # 20-way stack, backbone trains
+        net.to(device)
+        if world > 1:
+            parallel.broadcast_module(net)
+        defaults = None
+    else:
+        net = build_model(device, world, weights_path, Path(args.result_dir) / 'classification' / args.weights)
+        defaults = net.default_bboxes.to(device)
 
     if params_path.exists():
         print('Params loaded.')
@@ -114,8 +125,12 @@ def main():
             return
         for i in range(args.steps_per_epoch):
             seed = epoch * 100003 + i
-            yield (torch.from_numpy(synth.images(seed, args.batch_size * world, args.imsize)[lo:hi]).to(device),
-                   torch.from_numpy(synth.targets(seed, args.batch_size * world)[lo:hi]).to(device))
+            ims = torch.from_numpy(synth.images(seed, args.batch_size * world, args.imsize)[lo:hi]).to(device)
+            if classify:
+                labels = (synth.uniform(seed, 7, args.batch_size * world)[lo:hi] * 20).astype('int64')
+                yield ims, torch.nn.functional.one_hot(torch.from_numpy(labels), 20).float().to(device)
+            else:
+                yield ims, torch.from_numpy(synth.targets(seed, args.batch_size * world)[lo:hi]).to(device)
 
     for epoch in range(1 + start_epoch, args.epochs + start_epoch + 1):
         running = torch.zeros((), device=device)
@@ -134,10 +149,17 @@ def main():
             ims, gts, ready = cur
             n_steps += 1
             optimizer.zero_grad()
-            outputs = net(ims, ready_event=ready)
-            loss = net.loss(outputs=outputs, targets=gts, default_bboxes=defaults)
+            if classify:
+                outputs = net(ims)
+                loss = net.loss(outputs=outputs, targets=gts, nll=True)
+            else:
+                outputs = net(ims, ready_event=ready)
+                loss = net.loss(outputs=outputs, targets=gts, default_bboxes=defaults)
             cur = fetch()
             loss.backward()
+            if classify and world > 1:          # the engine's hook reduces the feature gradients; the classifier stack's are separate tensors
+                for prm in net._head().parameters():
+                    torch.distributed.all_reduce(prm.grad)
             optimizer.step()
             running += loss.detach()
         local_loss = running.item() / max(n_steps, 1)

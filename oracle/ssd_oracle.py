@@ -417,6 +417,83 @@ def train_step(sd, opt_state, images, targets_np, df, lr=1e-3, wd=5e-4, num_clas
 
 
 # ----------------------------------------------------------------------------
+# VGG16 classifier (src/model/vgg16.py:7-130): reference-keyed state dict, forward on torch CPU ops, the literal loss
+# ----------------------------------------------------------------------------
+def vgg16_init_state(seed=5, num_classes=20, head='classifier2'):
+    """State dict with the reference VGG16's keys (features.<idx>.*, classifier.*, classifier2.*).  Hash-seeded: kaiming fan_out
+    pseudo-normal convs, BN gamma 1 / beta 0 / stats 0, 1; the stack named by `head` uniform(-0.01, 0.01) weights and small biases,
+    the other stack zeros as stride-0 views (it is never used by forward(); a real tensor would be 0.5 GB)."""
+    import torch
+    from object_detection_torch2_amd import synth
+    sd, stream, idx, cin = {}, 300, 0, 3
+    for v in VGG_CFG:
+        if v in ('M', 'M_P'):
+            idx += 1
+            continue
+        std = math.sqrt(2.0 / (v * 9))
+        sd[f'features.{idx}.weight'] = torch.from_numpy((synth.pseudo_normal(seed, stream, v * cin * 9) * std).astype(f32).reshape(v, cin, 3, 3))
+        stream += 1
+        sd[f'features.{idx}.bias'] = torch.zeros(v)
+        sd[f'features.{idx + 1}.weight'] = torch.ones(v); sd[f'features.{idx + 1}.bias'] = torch.zeros(v)
+        sd[f'features.{idx + 1}.running_mean'] = torch.zeros(v); sd[f'features.{idx + 1}.running_var'] = torch.ones(v)
+        sd[f'features.{idx + 1}.num_batches_tracked'] = torch.tensor(0, dtype=torch.long)
+        idx, cin = idx + 3, v
+    for name, last in (('classifier', 1000), ('classifier2', num_classes)):
+        for i, (o, c) in zip((0, 3, 6), ((4096, 25088), (4096, 4096), (last, 4096))):
+            if name == head:
+                sd[f'{name}.{i}.weight'] = torch.from_numpy(((synth.uniform(seed, stream, o * c) - 0.5) * 0.02).astype(f32).reshape(o, c))
+                sd[f'{name}.{i}.bias'] = torch.from_numpy(((synth.uniform(seed, stream + 1, o) - 0.5) * 0.2).astype(f32))
+                stream += 2
+            else:
+                sd[f'{name}.{i}.weight'] = torch.zeros(1).expand(o, c)
+                sd[f'{name}.{i}.bias'] = torch.zeros(1).expand(o)
+    return sd
+
+
+def dropout_mask(seed, stream, n, p=0.5):
+    """The device pass's mask (csrc/classifier.hip): keep where the 24-bit counter-hash uniform >= p; returned already scaled by
+    1 / (1 - p).  (torch's own Philox stream is not reproduced: which units drop is unpinned by nature.)"""
+    from object_detection_torch2_amd import synth
+    keep = (synth.hash_u32(seed, stream, n) >> np.uint64(8)) >= np.uint64(int(p * 16777216.0))
+    return keep.astype(f32) * f32(1.0 / (1.0 - p))
+
+
+def vgg16_forward(sd, x, head='classifier2', training=True, masks=None):
+    """vgg16.py:85-101: normalize -> features -> x.view(N, -1) -> classifier stack.  masks: None = no dropout (eval-mode Dropout
+    modules), else the two (N, 4096) scaled masks applied after the ReLUs."""
+    import torch
+    import torch.nn.functional as F
+    mean = torch.tensor(MEAN, dtype=torch.float32).reshape(1, 3, 1, 1)
+    std = torch.tensor(STD, dtype=torch.float32).reshape(1, 3, 1, 1)
+    x = x.sub(mean).div(std)
+    idx = 0
+    for v in VGG_CFG:
+        if v in ('M', 'M_P'):
+            x = F.max_pool2d(x, 2, 2, padding=1 if v == 'M_P' else 0)
+            idx += 1
+            continue
+        p, q = f'features.{idx}', f'features.{idx + 1}'
+        x = F.conv2d(x, sd[p + '.weight'], sd[p + '.bias'], padding=1)
+        if training:
+            sd[q + '.num_batches_tracked'] += 1
+        x = F.relu(F.batch_norm(x, sd[q + '.running_mean'], sd[q + '.running_var'], sd[q + '.weight'], sd[q + '.bias'], training=training,
+                                momentum=0.1, eps=1e-5))
+        idx += 3
+    x = x.reshape(x.shape[0], -1)
+    for k, i in enumerate((0, 3)):
+        x = F.relu(F.linear(x, sd[f'{head}.{i}.weight'], sd[f'{head}.{i}.bias']))
+        if masks is not None:
+            x = x * masks[k]
+    return F.linear(x, sd[f'{head}.6.weight'], sd[f'{head}.6.bias'])
+
+
+def vgg16_loss(outputs, targets):
+    """vgg16.py:127-129, literally (no minus sign): mean_n sum_c t * log_softmax(outputs)."""
+    import torch.nn.functional as F
+    return (targets * F.log_softmax(outputs, dim=1)).sum(dim=1).mean()
+
+
+# ----------------------------------------------------------------------------
 # batch augmentation (src/augmentation/random.py:6-42 as the reference runs it: train.py:32-36 puts RandomColorJitter BEFORE
 # ToTensor, i.e. torchvision's ColorJitter on a PIL image -> PIL.ImageEnhance for brightness / contrast / saturation, an HSV
 # round trip for hue, uint8 after every operation; then PIL hflip, ToTensor (x / 255) and RandomErasing with value 0).

@@ -341,6 +341,49 @@ def gen_data():
     print('G11 data-path fixtures ok')
 
 
+def gen_vgg16():
+    """G13: the reference's VGG16 (model/vgg16.py) with transfer_learning=True on a 200-px batch (the only input sizes its
+    Linear(512*7*7) accepts are 184..215 px): logits, the literal loss and its gradients w.r.t. the classifier2 stack, with the
+    Dropout modules in eval mode (their masks come from torch's RNG: unpinnable) and BatchNorm in train mode like everywhere else.
+    The weights file (hash-seeded, ~0.6 GB because of classifier2.0) lives in a temporary directory and is never committed."""
+    import tempfile
+    from model import VGG16 as RefVGG16
+    sd = O.vgg16_init_state(seed=5, num_classes=20)
+    x = torch.from_numpy(synth.images(77, 2, 200))
+    tgt = torch.zeros(2, 20); tgt[0, 3] = 1; tgt[1, 11] = 1
+    with tempfile.TemporaryDirectory(dir=str(ROOT / 'gpurun_out') if (ROOT / 'gpurun_out').exists() else None) as tmp:
+        path = pathlib.Path(tmp) / 'vgg16_cls.pth'
+        torch.save(sd, path)
+        net = RefVGG16(weights_path=path, num_classes=20, transfer_learning=True)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.eval()
+    out = net(x)
+    loss = net.loss(out, tgt)
+    loss.backward()
+    sdo = {k: v.clone() for k, v in O.vgg16_init_state(seed=5, num_classes=20).items() if not k.startswith('classifier.')}
+    for k in sdo:
+        if k.startswith('classifier2.'):
+            sdo[k].requires_grad_(True)
+    out_o = O.vgg16_forward(sdo, x, 'classifier2', training=True, masks=None)
+    loss_o = O.vgg16_loss(out_o, tgt)
+    loss_o.backward()
+    print('VGG16 logits max|ref-oracle| =', (out - out_o).abs().max().item(), ' loss', loss.item(), loss_o.item())
+    assert torch.equal(out, out_o) and loss.item() == loss_o.item()
+    fx = dict(logits=out.detach().numpy(), loss=np.float64(loss.item()))
+    for i in (0, 3, 6):
+        gw, gb = net.classifier2[i].weight.grad, net.classifier2[i].bias.grad
+        assert torch.allclose(gw, sdo[f'classifier2.{i}.weight'].grad, rtol=1e-5, atol=1e-9)
+        fx[f'gw_{i}'] = gw.numpy().reshape(-1)[::(997 if i < 6 else 7)].copy()
+        fx[f'gb_{i}'] = gb.numpy().copy()
+    rm = net.features[1].running_mean
+    fx['bn0_running_mean'] = rm.numpy().copy()
+    # the reference's own train.py cannot reach this model: VGG16 has no train_params() (train.py:97)
+    fx['ref_has_train_params'] = np.int64(hasattr(net, 'train_params'))
+    np.savez_compressed(OUT / 'g13_vgg16.npz', **fx)
+    print('G13 VGG16 classifier fixtures ok')
+
+
 def gen_augment():
     """G12: the pixel arithmetic of the reference's colour jitter as it really runs -- train.py:32-36 applies RandomColorJitter
     BEFORE ToTensor, so torchvision's ColorJitter works on the PIL image: PIL.ImageEnhance for brightness / contrast / saturation,
@@ -398,7 +441,9 @@ def gen_augment():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['post', 'fwd', 'eval', 'data', 'augment']
+    which = sys.argv[1:] or ['post', 'fwd', 'eval', 'data', 'augment', 'vgg16']
+    if 'vgg16' in which:
+        gen_vgg16()
     if 'augment' in which:
         gen_augment()
     if 'data' in which:

@@ -91,3 +91,28 @@ def test_forward_and_stats(golden):
     with torch.no_grad():
         ye = O.forward(sd, x, training=False).numpy()
     assert np.abs(ye[:, ::7] - fx['fwd_eval_rows']).max() < 1e-4
+
+
+def test_vgg16_oracle_matches_reference_golden(golden):
+    """G13: the oracle's VGG16 restatement (model/vgg16.py:85-130) against the reference's own module run on CPU at generation time
+    (logits and literal loss bit-equal there; here the committed samples of the logits, loss and classifier2 gradients)."""
+    import torch
+    from object_detection_torch2_amd import synth
+    fx = golden('g13_vgg16.npz')
+    sd = {k: v.clone() for k, v in O.vgg16_init_state(seed=5, num_classes=20).items() if not k.startswith('classifier.')}
+    for k in sd:
+        if k.startswith('classifier2.'):
+            sd[k].requires_grad_(True)
+    x = torch.from_numpy(synth.images(77, 2, 200))
+    tgt = torch.zeros(2, 20); tgt[0, 3] = 1; tgt[1, 11] = 1
+    torch.set_num_threads(8)
+    out = O.vgg16_forward(sd, x, 'classifier2', training=True, masks=None)
+    loss = O.vgg16_loss(out, tgt)
+    loss.backward()
+    assert np.allclose(out.detach().numpy(), fx['logits'], rtol=1e-5, atol=1e-6) and abs(loss.item() - float(fx['loss'])) < 1e-6
+    for i in (0, 3, 6):
+        assert np.allclose(sd[f'classifier2.{i}.weight'].grad.numpy().reshape(-1)[::(997 if i < 6 else 7)], fx[f'gw_{i}'], rtol=1e-4, atol=1e-9)
+        assert np.allclose(sd[f'classifier2.{i}.bias'].grad.numpy(), fx[f'gb_{i}'], rtol=1e-4, atol=1e-9)
+    assert np.allclose(sd['features.1.running_mean'].numpy(), fx['bn0_running_mean'], rtol=1e-5, atol=1e-8)
+    m = O.dropout_mask(9, 0, 1000)
+    assert set(np.unique(m).tolist()) == {0.0, 2.0} and 0.4 < (m > 0).mean() < 0.6
