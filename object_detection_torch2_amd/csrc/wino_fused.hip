@@ -77,6 +77,7 @@ struct WfArgs {
     float* stats;
     int H, W, C, Cout, KT, NB, MB;
     unsigned x_bytes;
+    int skew;         // start delay per group of 8 blocks, in units of 1,024 cycles (0 = none): see the kernel
 };
 
 // U[xi] = (G g G^T)[xi], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; same operation order as winograd_weight_kernel
@@ -177,6 +178,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         mb0 = blockIdx.x / a.NB;
     }
     if (mb0 >= a.MB) return;                 // fewer tile blocks than groups (whole block: uniform)
+    // Equal items keep 256 persistent blocks in lockstep: every CU stores its 64 KiB of output (and issues its strip DMAs) in the
+    // same microsecond and HBM sees bursts with idle time between them.  A start delay that grows with the block id spreads them.
+    for (int k = (int)(blockIdx.x >> 3) * a.skew; k > 0; --k) __builtin_amdgcn_s_sleep(16);
     const int cnt = (a.MB - mb0 + mbstep - 1) / mbstep;
     const int n0 = nb * WF_COUT;
     const int KT = (ABL & 16) ? 4 : a.KT;
@@ -516,6 +520,12 @@ int ssdhip_wino_fused_conv(const float* x, const float* upk, const float* bias, 
     a.MB = ssdhip_wino_fused_stat_rows(N, H, W);
     SSDHIP_REQUIRE(a.MB > 0 && a.NB <= 256, "wino_fused_conv: bad shape");
     a.x_bytes = (unsigned)((int64_t)N * H * W * Cin * 4);
+    // measured (scripts/wf_bench.py, SKEWS=...): conv_1_2 (8 K-steps per 64 KiB of output) 1.48 -> 1.29 ms with 2; layers with longer
+    // K loops or two channel tiles lose 1-2 % to the longer tail instead
+    a.skew = (a.KT <= 8 && a.NB == 1) ? 2 : 0;
+#ifdef SSDHIP_PROBES
+    if (const char* e = getenv("SSDHIP_WF_SKEW")) a.skew = atoi(e);
+#endif
     // persistent grid: one block per CU, a multiple of NB so that a block keeps its channel tile (and its weight slice in L2)
     const int64_t items = (int64_t)a.MB * a.NB;
     // (max_blocks > 0 leaves CUs to kernels of other streams: a block fills its CU's LDS and registers for the whole launch)

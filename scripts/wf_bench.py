@@ -29,6 +29,11 @@ for name, H, cin, cout in L:
     tiles = N * ((H + 1) // 2) ** 2
     wino = 2.0 * 16 * tiles * cin * cout
     best, med = timeit(lambda: ops.wino_fused_conv(x, w, b, in_scale=sc, in_shift=sh, want_stats=True, upk=upk))
+    for sk in [int(v) for v in os.environ.get('SKEWS', '').split(',') if v]:
+        os.environ['SSDHIP_WF_SKEW'] = str(sk)
+        ba, ma = timeit(lambda: ops.wino_fused_conv(x, w, b, in_scale=sc, in_shift=sh, want_stats=True, upk=upk))
+        del os.environ['SSDHIP_WF_SKEW']
+        print(f'    skew {sk}: min {ba:7.3f} med {ma:7.3f} ms ({wino / ma / 1e9:6.1f} TF executed)', flush=True)
     for abl in [int(v) for v in os.environ.get('ABLS', '').split(',') if v]:
         os.environ['SSDHIP_WF_ABL'] = str(abl)
         ba, ma = timeit(lambda: ops.wino_fused_conv(x, w, b, in_scale=sc, in_shift=sh, want_stats=True, upk=upk))
