@@ -242,6 +242,21 @@ int ssdhip_wino_fused_geo(int N, int H, int W, void* geo, void* stream);
 int ssdhip_wino_fused_conv(const float* x, const float* upk, const float* bias, const float* in_scale, const float* in_shift, float* z,
                            float* stats, const void* geo, int N, int H, int W, int Cin, int Cout, int max_blocks, void* stream);
 
+/* ---- BASELINE configs[3] / [4] (bf16 forward / backward with fp32 master weights), backbone forward: the 3x3/s1/p1 layers of
+ * model/vgg16.py:33 on bf16 activations kept in HBM, v_mfma_f32_32x32x16_bf16 with fp32 accumulation, fed by LDS-DMA from an image
+ * patch that serves all 9 taps.  Opt-in (SSD.set_compute_dtype('bf16')); never the fp32 headline path.
+ * a = ACTIVATED input (BatchNorm + ReLU applied), bf16, NHWC with a one-pixel zero halo: (N, H+2, W+2, Cin) inside a zero-initialised
+ * allocation of ssdhip_conv_bf16_act_bytes(N,H,W,Cin) bytes (the slack behind the tensor is read, never written); Cin % 32 == 0,
+ * W >= 14.  wpk = ssdhip_conv_bf16_pack(w OIHW (Cout,Cin,3,3) fp32), ssdhip_conv_bf16_weight_bytes(Cout,Cin) bytes, Cout % 64 == 0.
+ * z (N,H,W,Cout) = conv + bias, fp32 (z_bf16 = 0) or bf16 (1); stats NULL or (ssdhip_conv_bf16_stat_rows(N,H,W), Cout, 2) fp32
+ * partial sum / sum of squares of the fp32 values.  max_blocks as in ssdhip_wino_fused_conv.  Returns the stats rows or < 0.   */
+int64_t ssdhip_conv_bf16_weight_bytes(int Cout, int Cin);
+int ssdhip_conv_bf16_pack(const float* w_oihw, void* wpk, int Cout, int Cin, void* stream);
+int64_t ssdhip_conv_bf16_act_bytes(int N, int H, int W, int C);
+int ssdhip_conv_bf16_stat_rows(int N, int H, int W);
+int ssdhip_conv_bf16(const void* a, const void* wpk, const float* bias, void* z, int z_bf16, float* stats, int N, int H, int W, int Cin,
+                     int Cout, int max_blocks, void* stream);
+
 /* ---- 8(f)-4  full fine-tuning (train.py:69-74 un-freezes nothing; extension): backward of MaxPool2d(2,2,pad) over the
  * recomputed a = relu(z*scale+shift) (vgg16.py:28-35): dpooled (N,Ho,Wo,C) -> da (N,H,W,C), gradient to the first maximum
  * of each window in scan order (ATen rule).                                                                            */

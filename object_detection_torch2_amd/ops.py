@@ -143,6 +143,47 @@ def wino_fused_conv(x, w_oihw, bias=None, in_scale=None, in_shift=None, want_sta
     return z, stats
 
 
+def conv_bf16_pack(w_oihw):
+    """OIHW fp32 (Cout % 64 == 0, Cin % 32 == 0, 3, 3) -> the bf16 patch convolution's weight images (uint8 tensor)."""
+    _lib.require_gpu(w_oihw)
+    lib = _lib.load()
+    w = _lib.f32c(w_oihw)
+    cout, cin = w.shape[0], w.shape[1]
+    if tuple(w.shape[2:]) != (3, 3):
+        raise ValueError(f'conv_bf16_pack: 3x3 filters only, got {tuple(w.shape)}')
+    wpk = torch.empty(_lib.check(lib.ssdhip_conv_bf16_weight_bytes(cout, cin), 'conv_bf16_weight_bytes'), device=w.device, dtype=torch.uint8)
+    _lib.check(lib.ssdhip_conv_bf16_pack(_lib.ptr(w), _lib.ptr(wpk), cout, cin, _lib.stream()), 'conv_bf16_pack')
+    return wpk
+
+
+def haloed_bf16(N, H, W, C, device):
+    """Zero-initialised allocation for an activated bf16 NHWC tensor with a one-pixel zero halo, (buffer, view (N, H+2, W+2, C))."""
+    nbytes = _lib.check(_lib.load().ssdhip_conv_bf16_act_bytes(N, H, W, C), 'conv_bf16_act_bytes')
+    buf = torch.zeros(nbytes // 2, device=device, dtype=torch.bfloat16)
+    return buf, buf[: N * (H + 2) * (W + 2) * C].view(N, H + 2, W + 2, C)
+
+
+def conv_bf16(a_buf, shape, w_oihw, bias=None, want_stats=False, wpk=None, z_bf16=False, max_blocks=0):
+    """3x3/s1/p1 conv on the bf16 MFMA from a haloed activated bf16 input (haloed_bf16 buffer, shape = (N, H, W, Cin)):
+    -> (z (N,H,W,Cout) fp32 or bf16, stats (MB,Cout,2) fp32 or None)."""
+    _lib.require_gpu(a_buf, w_oihw)
+    lib = _lib.load()
+    N, H, W, C = shape
+    cout, cin = w_oihw.shape[0], w_oihw.shape[1]
+    if cin != C:
+        raise ValueError(f'conv_bf16: input has {C} channels, weights expect {cin}')
+    if a_buf.dtype != torch.bfloat16 or a_buf.numel() * 2 < _lib.check(lib.ssdhip_conv_bf16_act_bytes(N, H, W, C), 'conv_bf16_act_bytes'):
+        raise ValueError('conv_bf16: input must be the bf16 buffer of haloed_bf16(N, H, W, C)')
+    if wpk is None:
+        wpk = conv_bf16_pack(w_oihw)
+    z = torch.empty(N, H, W, cout, device=a_buf.device, dtype=torch.bfloat16 if z_bf16 else torch.float32)
+    stats = torch.empty(_lib.check(lib.ssdhip_conv_bf16_stat_rows(N, H, W), 'conv_bf16_stat_rows'), cout, 2, device=a_buf.device,
+                        dtype=torch.float32) if want_stats else None
+    _lib.check(lib.ssdhip_conv_bf16(_lib.ptr(a_buf), _lib.ptr(wpk), _lib.ptr(bias) if bias is not None else None, _lib.ptr(z), int(z_bf16),
+                                    _lib.ptr(stats) if stats is not None else None, N, H, W, C, cout, max_blocks, _lib.stream()), 'conv_bf16')
+    return z, stats
+
+
 def conv2d_dgrad(dy, w_oihw, in_hw, stride=1, pad=0, accumulate_into=None, tile=0, bf16=False):
     """dy (N,Ho,Wo,Cout_pad) -> dx (N,Hi,Wi,Cin): data gradient of conv2d(x, w, stride, pad)."""
     _lib.require_gpu(dy, w_oihw)

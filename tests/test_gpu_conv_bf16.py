@@ -1,0 +1,55 @@
+"""GPU: the bf16 patch convolution (csrc/conv_bf16.hip; BASELINE configs[3] / [4] backbone forward, model/vgg16.py:33) against
+torch's fp32 convolution of the SAME bf16-rounded operands: the products are exact in fp32, so only the summation order differs
+(tolerance 2e-5 of the largest output; a bf16 output adds its own rounding, 2^-8 relative)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+# (N, H, W, Cin, Cout, max_blocks): tiles of 16 x 32 for W > 125, flat below; max_blocks > 0 makes a block walk several items
+CASES = [(1, 130, 140, 64, 64, 0), (2, 150, 150, 64, 128, 0), (2, 150, 150, 64, 128, 8), (1, 127, 126, 32, 192, 16),
+         (2, 75, 75, 128, 256, 0), (3, 38, 38, 256, 128, 6), (2, 19, 19, 64, 64, 0), (1, 16, 14, 32, 64, 0), (4, 19, 125, 96, 64, 3)]
+
+
+def _case(N, H, W, Cin, Cout, seed=0):
+    from object_detection_torch2_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    x = torch.randn(N, H, W, Cin, generator=g).relu_().to(DEV).bfloat16()            # activated input: non-negative
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    buf, view = ops.haloed_bf16(N, H, W, Cin, DEV)
+    view[:, 1:-1, 1:-1, :] = x
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.bfloat16().float(), b, padding=1).permute(0, 2, 3, 1).contiguous()
+    return ops, buf, w, b, ref
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout,mb', CASES)
+def test_conv_bf16_matches_fp32_conv_of_rounded_operands(N, H, W, Cin, Cout, mb):
+    ops, buf, w, b, ref = _case(N, H, W, Cin, Cout)
+    z, stats = ops.conv_bf16(buf, (N, H, W, Cin), w, b, want_stats=True, max_blocks=mb)
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    assert (z - ref).abs().max().item() < 2e-5 * scale, ((z - ref).abs().max().item(), scale)
+    s = stats.double().sum(dim=0)
+    n = N * H * W
+    assert torch.allclose(s[:, 0] / n, ref.double().mean(dim=(0, 1, 2)), rtol=0, atol=2e-5 * scale)
+    assert torch.allclose(s[:, 1] / n, (ref.double() ** 2).mean(dim=(0, 1, 2)), rtol=1e-4)
+    zb, stats_b = ops.conv_bf16(buf, (N, H, W, Cin), w, b, want_stats=True, z_bf16=True, max_blocks=mb)
+    assert zb.dtype == torch.bfloat16 and (zb.float() - ref).abs().max().item() < 2 ** -8 * scale + 2e-5 * scale
+    assert torch.equal(stats_b, stats)                      # the statistics come from the fp32 values either way; deterministic
+
+
+def test_conv_bf16_rejects_bad_arguments():
+    from object_detection_torch2_amd import ops
+    buf, _ = ops.haloed_bf16(1, 20, 20, 32, DEV)
+    w = torch.zeros(64, 32, 3, 3, device=DEV)
+    with pytest.raises(ValueError):
+        ops.conv_bf16(buf, (1, 20, 20, 64), w)                               # channel mismatch
+    with pytest.raises(ValueError):
+        ops.conv_bf16(buf[:100], (1, 20, 20, 32), w)                         # not the haloed allocation
+    with pytest.raises(ValueError):
+        ops.conv_bf16_pack(torch.zeros(48, 32, 3, 3, device=DEV))            # Cout % 64
+    with pytest.raises(RuntimeError):
+        ops.conv_bf16(buf, (1, 20, 20, 32), torch.zeros(64, 32, 3, 3))       # no CPU fallback
