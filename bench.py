@@ -296,7 +296,7 @@ def main():
     def aggregate(records):
         agg = {}
         for r in records:
-            a = agg.setdefault(r['kernel'], dict(ms=0.0, flops=0.0, n=0, layers=set(), direct=0.0))
+            a = agg.setdefault(r['kernel'], dict(ms=0.0, flops=0.0, n=0, layers=set(), direct=0.0, peak=r.get('peak_tflops', FP32_MFMA_PEAK_TFLOPS)))
             a['ms'] += r['e0'].elapsed_time(r['e1']); a['flops'] += r['flops']; a['n'] += 1; a['layers'].add(r['layer'])
             a['direct'] += r.get('direct_flops', r['flops'])
         return agg
@@ -316,8 +316,9 @@ def main():
         if a['direct'] > a['flops'] * 1.01:
             notes.append('achieved/frac count the MFMA flops this kernel executes; the Winograd-domain GEMMs stand for '
                          f"{a['direct'] / a['flops']:.2f}x as many direct-convolution flops")
-        roof = dict(bound='mfma', kernel=name, achieved=round(ach, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-                    frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic, launches=a['n'],
+        peak = a['peak']          # fp32 MFMA peak, or the dense bf16 MFMA peak for the bf16 patch convolution (MI355X_MICROARCH.md)
+        roof = dict(bound='mfma', kernel=name, achieved=round(ach, 2), peak=peak, unit='TFLOP/s',
+                    frac=round(ach / peak, 4), traffic=traffic, launches=a['n'],
                     algorithmic_flop_per_launch=round(a['flops'] / a['n']),
                     avg_launch_ms=round(a['ms'] / a['n'], 4), layers=sorted(a['layers']),
                     conv_fwd_tflops_launches_over_10_gflop=round(sum(v['flops'] for v in agg.values()) / (sum(v['ms'] for v in agg.values()) * 1e-3) / 1e12, 2))
@@ -340,7 +341,7 @@ def main():
                 ach_x = ex['flops'] / (ex['ms'] * 1e-3) / 1e12
                 roof['timed_region'] = dict(achieved=roof['achieved'], frac=roof['frac'], avg_launch_ms=roof['avg_launch_ms'], launches=roof['launches'],
                                             what='HIP events around the launches inside the timed region, where three streams share the chip (a time-share, not the kernel alone)')
-                roof.update(achieved=round(ach_x, 2), frac=round(ach_x / FP32_MFMA_PEAK_TFLOPS, 4), avg_launch_ms=round(ex['ms'] / ex['n'], 4), launches=ex['n'],
+                roof.update(achieved=round(ach_x, 2), frac=round(ach_x / peak, 4), avg_launch_ms=round(ex['ms'] / ex['n'], 4), launches=ex['n'],
                             measured='HIP events around the same launches over 3 extra steps (after one unrecorded step) right after the timed region, streams serialised '
                                      '(agrees with the per-dispatch durations rocprofv3 reports for this command)')
         roof['note'] = '; '.join(notes) if notes else None

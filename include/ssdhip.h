@@ -257,6 +257,12 @@ int ssdhip_conv_bf16_stat_rows(int N, int H, int W);
 int ssdhip_conv_bf16(const void* a, const void* wpk, const float* bias, void* z, int z_bf16, float* stats, int N, int H, int W, int Cin,
                      int Cout, int max_blocks, void* stream);
 
+/* The producer side of ssdhip_conv_bf16's input: BatchNorm apply + ReLU (+ MaxPool2d(2,2,pool_pad) when pool != 0) of the pre-BN map
+ * z (N,H,W,C) fp32 (z_bf16 = 0) or bf16 (1), written as bf16 into the INTERIOR of the haloed tensor out (N, Ho+2, Wo+2, C) (vgg16.py:28-35);
+ * the halo and the slack of the allocation stay as the caller zero-initialised them.  C % 8 == 0.                               */
+int ssdhip_bn_relu_to_bf16(const void* z, int z_bf16, const float* scale, const float* shift, void* out, int N, int H, int W, int C, int pool,
+                           int pool_pad, void* stream);
+
 /* ---- 8(f)-4  full fine-tuning (train.py:69-74 un-freezes nothing; extension): backward of MaxPool2d(2,2,pad) over the
  * recomputed a = relu(z*scale+shift) (vgg16.py:28-35): dpooled (N,Ho,Wo,C) -> da (N,H,W,C), gradient to the first maximum
  * of each window in scan order (ATen rule).                                                                            */

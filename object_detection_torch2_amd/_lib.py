@@ -99,6 +99,7 @@ SIGNATURES = {
     'ssdhip_conv_bf16_act_bytes': (c_int64, [c_int, c_int, c_int, c_int]),
     'ssdhip_conv_bf16_stat_rows': (c_int, [c_int, c_int, c_int]),
     'ssdhip_conv_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'ssdhip_bn_relu_to_bf16': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ssdhip_bn_relu_pool_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ssdhip_nhwc_flatten': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ssdhip_relu_dropout': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, ctypes.c_uint32, c_int, c_void_p]),

@@ -77,6 +77,58 @@ __global__ void conv_bf16_pack_kernel(const float* __restrict__ w, __bf16* __res
     }
 }
 
+
+// BatchNorm apply + ReLU (+ MaxPool2d(2, 2, pad)) of a pre-BN map z (fp32 or bf16) -> the activated bf16 tensor with a zero halo
+// that conv_bf16_kernel reads (model/vgg16.py:28-35).  One thread = one output pixel x 8 channels (one 16-B store).  The value
+// is relu(fma(z, scale, shift)) rounded to nearest even: exactly what the implicit-GEMM bf16 template forms when it stages z.
+struct F8 { float v[8]; };
+template <bool ZBF16>
+__device__ __forceinline__ F8 load8(const void* z, int64_t idx8) {
+    F8 r;
+    if (ZBF16) {
+        const bf16x8 t = reinterpret_cast<const bf16x8*>(z)[idx8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r.v[k] = (float)t[k];
+    } else {
+        const float4 lo = reinterpret_cast<const float4*>(z)[2 * idx8], hi = reinterpret_cast<const float4*>(z)[2 * idx8 + 1];
+        r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w; r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+    }
+    return r;
+}
+template <bool ZBF16, bool POOL>
+__global__ __launch_bounds__(256) void bn_relu_to_bf16_kernel(const void* __restrict__ z, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              __bf16* __restrict__ out, int H, int W, int C8, int Ho, int Wo, int pad, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c8 = (int)(i % C8);
+    int64_t pix = i / C8;
+    const int wo = (int)(pix % Wo);
+    pix /= Wo;
+    const int ho = (int)(pix % Ho);
+    const int64_t n = pix / Ho;
+    const F8 sc = load8<false>(scale, c8), sh = load8<false>(shift, c8);
+    float m[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[k] = 0.f;          // ReLU output >= 0 and every window holds a real pixel: 0 is the identity of the max
+#pragma unroll
+    for (int dy = 0; dy < (POOL ? 2 : 1); ++dy) {
+        const int h = POOL ? ho * 2 - pad + dy : ho;
+        if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+        for (int dx = 0; dx < (POOL ? 2 : 1); ++dx) {
+            const int w = POOL ? wo * 2 - pad + dx : wo;
+            if ((unsigned)w >= (unsigned)W) continue;
+            const F8 v = load8<ZBF16>(z, ((n * H + h) * W + w) * C8 + c8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], fmaxf(fmaf(v.v[k], sc.v[k], sh.v[k]), 0.f));
+        }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (__bf16)m[k];
+    reinterpret_cast<bf16x8*>(out)[((n * (Ho + 2) + ho + 1) * (Wo + 2) + wo + 1) * C8 + c8] = o;
+}
+
 template <int MT, int NT, int WN, bool ZBF16>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_bf16_kernel(CbArgs a) {
     constexpr int WM = 8 / WN;
@@ -392,6 +444,27 @@ int ssdhip_conv_bf16(const void* a, const void* wpk, const float* bias, void* z,
     }
     SSDHIP_CHECK_LAUNCH();
     return g.MB;
+}
+
+int ssdhip_bn_relu_to_bf16(const void* z, int z_bf16, const float* scale, const float* shift, void* out, int N, int H, int W, int C, int pool,
+                           int pool_pad, void* stream) {
+    SSDHIP_REQUIRE(z && scale && shift && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "bn_relu_to_bf16: bad arguments (C % 8 == 0)");
+    SSDHIP_REQUIRE(pool_pad == 0 || pool_pad == 1, "bn_relu_to_bf16: pool padding 0 or 1");
+    hipStream_t st = (hipStream_t)stream;
+    const int C8 = C / 8;
+    const int Ho = pool ? (H + 2 * pool_pad - 2) / 2 + 1 : H, Wo = pool ? (W + 2 * pool_pad - 2) / 2 + 1 : W;
+    const int64_t total = (int64_t)N * Ho * Wo * C8;
+    const dim3 grid(cdiv(total, 256)), block(256);
+    __bf16* o = reinterpret_cast<__bf16*>(out);
+    if (pool) {
+        if (z_bf16) hipLaunchKernelGGL((bn_relu_to_bf16_kernel<true, true>), grid, block, 0, st, z, scale, shift, o, H, W, C8, Ho, Wo, pool_pad, total);
+        else hipLaunchKernelGGL((bn_relu_to_bf16_kernel<false, true>), grid, block, 0, st, z, scale, shift, o, H, W, C8, Ho, Wo, pool_pad, total);
+    } else {
+        if (z_bf16) hipLaunchKernelGGL((bn_relu_to_bf16_kernel<true, false>), grid, block, 0, st, z, scale, shift, o, H, W, C8, Ho, Wo, 0, total);
+        else hipLaunchKernelGGL((bn_relu_to_bf16_kernel<false, false>), grid, block, 0, st, z, scale, shift, o, H, W, C8, Ho, Wo, 0, total);
+    }
+    SSDHIP_CHECK_LAUNCH();
+    return SSDHIP_OK;
 }
 
 }  // extern "C"

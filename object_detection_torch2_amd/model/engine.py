@@ -225,6 +225,17 @@ class Engine:
                 and min(g['hi'], g['wi']) >= 70 and N * g['hi'] * g['wi'] * max(c.cin * 4, c.cout) < (1 << 31)
                 and N * ((g['hi'] + 1) // 2) < 65536)
 
+    def _patch_ok(self, i, N, geo):
+        """bf16 mode (BASELINE configs[3] / [4]): frozen 3x3/s1/p1 backbone layers run on the bf16 patch convolution (conv_bf16.hip),
+        reading an ACTIVATED bf16 tensor with a zero halo that the producer's apply pass wrote -- the activations of the backbone are
+        bf16 in HBM.  The trainable tail keeps the implicit-GEMM bf16 template (fp32 tensors, operands rounded at staging)."""
+        if not self.bf16 or i <= 0 or i >= min(self.tail_start, len(self.stages)) or os.environ.get('SSD_NO_BF16_PATCH') == '1':
+            return False
+        c, g = self.stages[i].conv, geo[i]
+        return (c.frozen and not c.is_head and c.k == 3 and c.stride == 1 and c.pad == 1 and c.cin % 32 == 0 and c.cin >= 32
+                and c.cout % 64 == 0 and g['wi'] >= 14 and self.lib.ssdhip_conv_bf16_act_bytes(N, g['hi'], g['wi'], c.cin) < (1 << 31)
+                and N * g['hi'] * g['wi'] * c.cout < (1 << 31))
+
     @staticmethod
     def _wino_ok(g):
         return g['hi'] <= 160 and g['wi'] <= 160        # from the 150x150 maps down (x1.1 there, x1.8 at 38x38); 300x300 is transform-traffic-bound
@@ -461,7 +472,31 @@ class Engine:
                     for ev in self._readers.pop(i, ()):      # last step's readers of this stage's output / BN state
                         bb.wait_event(ev)
                 st = _lib.stream()
-                if self._fused_ok(c, g, N):
+                patch = self._patch_ok(i, N, geo)
+                nxt_patch = self._patch_ok(i + 1, N, geo)
+                # z of a patch layer is bf16 when only the next layer's apply pass reads it (no head, no fp32 consumer)
+                z_bf16 = patch and nxt_patch and s.head is None and os.environ.get('SSD_BF16_Z', 'bf16') == 'bf16'
+                if patch:
+                    w1, b1 = self._weight(c)
+                    key = (w1.data_ptr(), w1._version, 0)
+                    if getattr(c, 'cb_img', None) is None or c.cb_img.device != w1.device:
+                        c.cb_img = torch.empty(self.lib.ssdhip_conv_bf16_weight_bytes(c.cout, c.cin), device=w1.device, dtype=torch.uint8)
+                        c.cb_key = None
+                    if c.cb_key != key:
+                        _lib.check(self.lib.ssdhip_conv_bf16_pack(_lib.ptr(w1), _lib.ptr(c.cb_img), c.cout, c.cin, st), f'conv_bf16_pack {c.name}')
+                        c.cb_key = key
+                    if self.prof is not None:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                    rows = _lib.check(self.lib.ssdhip_conv_bf16(_lib.ptr(cur), _lib.ptr(c.cb_img), _lib.ptr(b1) if b1 is not None else None, _lib.ptr(z),
+                                                                int(z_bf16), _lib.ptr(ws['partial']) if training else None, N, g['hi'], g['wi'],
+                                                                c.cin, c.cout, self._wf_blocks, st), f'conv2d {c.name}')
+                    if self.prof is not None:
+                        e1.record()
+                        fl = 2.0 * N * g['hi'] * g['wi'] * c.cin * c.cout * 9
+                        self.prof.append(dict(layer=c.name + ' (bf16 patch)', e0=e0, e1=e1, flops=fl, peak_tflops=2500.0,
+                                              kernel='conv_bf16_kernel<%s, %s>' % ('4, 2, 2' if c.cout % 128 == 0 else '2, 2, 1', 'true' if z_bf16 else 'false')))
+                elif self._fused_ok(c, g, N):
                     # conv_1_2 .. conv_3_3 (300x300 .. 75x75 maps): the one-kernel Winograd form (wino_fused.hip); nothing of the
                     # Winograd domain in HBM.  Measured against the paths below (scripts/wf_bench.py, batch 32): conv_1_2 1.57 vs 1.80 ms,
                     # conv_2_1 0.71 vs 0.86, conv_2_2 1.17 vs 1.6-1.9, conv_3_1 0.71 vs 0.79, conv_3_2/3 1.18 vs 1.23; from the 38x38
@@ -541,7 +576,18 @@ class Engine:
                                                             _lib.ptr(bnm.running_var), bnm.eps, c.cout, _lib.ptr(bst['scale']),
                                                             _lib.ptr(bst['shift']), st), f'batch_norm(eval) {s.bn_name}')
                 act_xs = (bst['scale'], bst['shift'])       # act_L = relu(z * scale + shift), never materialised
-                if s.pool_pad is not None:
+                if nxt_patch:
+                    # the next layer reads bf16: BN apply + ReLU (+ pool) into the interior of its haloed input, in one pass
+                    abf = b.setdefault('abf', {}).get(i + 1)
+                    if abf is None:
+                        cn, gn = self.stages[i + 1].conv, geo[i + 1]
+                        abf = torch.zeros(self.lib.ssdhip_conv_bf16_act_bytes(N, gn['hi'], gn['wi'], cn.cin) // 2, device=dev, dtype=torch.bfloat16)
+                        b['abf'][i + 1] = abf
+                    _lib.check(self.lib.ssdhip_bn_relu_to_bf16(_lib.ptr(z), int(z_bf16), _lib.ptr(bst['scale']), _lib.ptr(bst['shift']), _lib.ptr(abf),
+                                                               N, g['ho'], g['wo'], c.cout, int(s.pool_pad is not None), s.pool_pad or 0, st),
+                               f'bn_relu_to_bf16 after {c.name}')
+                    cur, cur_xs = abf, None
+                elif s.pool_pad is not None:
                     pooled = b['pooled'][i]
                     _lib.check(self.lib.ssdhip_bn_relu_pool(_lib.ptr(z), _lib.ptr(bst['scale']), _lib.ptr(bst['shift']), _lib.ptr(pooled),
                                                             N, g['ho'], g['wo'], c.cout, 1, s.pool_pad, st), f'pool after {c.name}')

@@ -184,6 +184,22 @@ def conv_bf16(a_buf, shape, w_oihw, bias=None, want_stats=False, wpk=None, z_bf1
     return z, stats
 
 
+def bn_relu_to_bf16(z, scale, shift, pool_pad=None):
+    """relu(z * scale + shift) (then MaxPool2d(2, 2, pool_pad) unless pool_pad is None) of z (N,H,W,C) fp32 or bf16 -> the haloed
+    activated bf16 input of conv_bf16: (buffer, view (N, Ho+2, Wo+2, C))."""
+    _lib.require_gpu(z, scale, shift)
+    if z.dtype not in (torch.float32, torch.bfloat16) or not z.is_contiguous():
+        raise ValueError('bn_relu_to_bf16: z must be a contiguous fp32 or bf16 tensor')
+    N, H, W, C = z.shape
+    pool = pool_pad is not None
+    pad = int(pool_pad or 0)
+    Ho, Wo = ((H + 2 * pad - 2) // 2 + 1, (W + 2 * pad - 2) // 2 + 1) if pool else (H, W)
+    buf, view = haloed_bf16(N, Ho, Wo, C, z.device)
+    _lib.check(_lib.load().ssdhip_bn_relu_to_bf16(_lib.ptr(z), int(z.dtype == torch.bfloat16), _lib.ptr(_lib.f32c(scale)), _lib.ptr(_lib.f32c(shift)),
+                                                  _lib.ptr(buf), N, H, W, C, int(pool), pad, _lib.stream()), 'bn_relu_to_bf16')
+    return buf, view
+
+
 def conv2d_dgrad(dy, w_oihw, in_hw, stride=1, pad=0, accumulate_into=None, tile=0, bf16=False):
     """dy (N,Ho,Wo,Cout_pad) -> dx (N,Hi,Wi,Cin): data gradient of conv2d(x, w, stride, pad)."""
     _lib.require_gpu(dy, w_oihw)

@@ -53,3 +53,27 @@ def test_conv_bf16_rejects_bad_arguments():
         ops.conv_bf16_pack(torch.zeros(48, 32, 3, 3, device=DEV))            # Cout % 64
     with pytest.raises(RuntimeError):
         ops.conv_bf16(buf, (1, 20, 20, 32), torch.zeros(64, 32, 3, 3))       # no CPU fallback
+
+
+@pytest.mark.parametrize('zdt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('pool_pad', [None, 0, 1])
+def test_bn_relu_to_bf16_apply_pass(zdt, pool_pad):
+    """BN apply + ReLU (+ MaxPool2d(2,2,pad)) into the haloed bf16 tensor (vgg16.py:28-35): values within one bf16 rounding of
+    torch's fp32 result (fma vs mul + add can move a value across a rounding boundary), halo and slack untouched (zero)."""
+    from object_detection_torch2_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(3)
+    N, H, W, C = 2, 37, 41, 72
+    z = torch.randn(N, H, W, C, generator=g).to(DEV).to(zdt)
+    sc, sh = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.3).to(DEV)
+    buf, view = ops.bn_relu_to_bf16(z, sc, sh, pool_pad=pool_pad)
+    a = torch.relu(z.float() * sc + sh).permute(0, 3, 1, 2)
+    if pool_pad is not None:
+        a = F.max_pool2d(a, 2, 2, padding=pool_pad)
+    ref = a.permute(0, 2, 3, 1)
+    assert tuple(view.shape) == (N, ref.shape[1] + 2, ref.shape[2] + 2, C)
+    got = view[:, 1:-1, 1:-1, :].float()
+    assert (got - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item()
+    assert ((got - ref).abs() <= 2 ** -8 * ref.abs() + 1e-6).all()
+    halo = view.clone()
+    halo[:, 1:-1, 1:-1, :] = 0
+    assert halo.abs().max().item() == 0 and buf[view.numel():].abs().max().item() == 0
