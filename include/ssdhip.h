@@ -172,6 +172,8 @@ typedef struct {
     int32_t dy_row;           /* floats per pixel row of dy (>= Cout, multiple of 4; channel padding) */
     int32_t dw_cin;           /* channels of dw_oihw's layout if smaller than Cin (RGB input padded to 4 in x), else 0 */
     const float* wino_v;      /* Winograd variant only: precomputed input transform V (16,Tp,Cin) of x, or NULL */
+    int32_t compute;          /* ssdhip_conv2d_wgrad only: 0 = exact fp32 MFMA; 1 = operands rounded to bf16 at LDS staging, bf16 MFMA,
+                                 fp32 accumulation and fp32 result (BASELINE configs[3]; opt-in, never the headline) */
 } ssdhip_wgrad_params;
 int64_t ssdhip_conv2d_wgrad_ws_bytes(const ssdhip_wgrad_params* p);
 int ssdhip_conv2d_wgrad(const ssdhip_wgrad_params* p, void* stream);

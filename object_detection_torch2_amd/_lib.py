@@ -34,7 +34,7 @@ class WgradParams(Structure):
                 ('dw_oihw', c_void_p), ('dbias', c_void_p), ('ws', c_void_p), ('dy_batch_stride', c_int64),
                 ('N', c_int32), ('Hi', c_int32), ('Wi', c_int32), ('Cin', c_int32), ('Ho', c_int32), ('Wo', c_int32),
                 ('Cout', c_int32), ('R', c_int32), ('S', c_int32), ('stride', c_int32), ('pad', c_int32), ('dy_row', c_int32),
-                ('dw_cin', c_int32), ('wino_v', c_void_p)]
+                ('dw_cin', c_int32), ('wino_v', c_void_p), ('compute', c_int32)]
 
 
 # every symbol include/ssdhip.h declares: name -> (restype, argtypes)

@@ -182,6 +182,153 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
 }
 
+// BASELINE configs[3] (bf16 forward / backward, fp32 master weights): the same weight gradient with both operands rounded to bf16
+// on the way into LDS and the products on v_mfma_f32_32x32x16_bf16 (fp32 accumulation, fp32 slabs, same split-K and reduce pass).
+// Both operands are pixel-major in memory while the MFMA wants 8 consecutive k = pixels per lane: the LDS images stay pixel-major
+// ([32 pixel rows][128 channels] bf16, 256-B rows, 16-B chunk ch of row r at ch ^ (((r & 3) << 2) | ((r >> 2) & 3))) and the
+// fragments are read TRANSPOSED with ds_read_b64_tr_b16 (4 pixel rows x 16 channels per 16 lanes; conflict-free with that XOR).
+// The matrix pipe is 16x faster than on the fp32 kernel, so the launch is bound by its staging (global loads, BN.ReLU, rounding).
+typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+typedef short ws16x4 __attribute__((ext_vector_type(4)));
+typedef short ws16x8 __attribute__((ext_vector_type(8)));
+typedef float wf32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) ws16x4* lds_s16x4_t;
+
+template <bool XFORM>
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a) {
+    constexpr int IMG = TK * 256;                                    // one operand image: 32 pixel rows x 128 channels bf16
+    __shared__ __attribute__((aligned(16))) char lds[2 * 2 * IMG];   // [buffer][dy, a]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    int b = blockIdx.x;
+    const int ib = b % a.IB; b /= a.IB;
+    const int cb = b % a.CB; b /= a.CB;
+    const int tap = b % a.taps; b /= a.taps;
+    const int split = b;
+    const int co0 = cb * TM, ci0 = ib * TN;
+    const int r = tap / a.KS, s = tap - r * a.KS;
+    const float* xbase = a.x;
+    const float* dybase = a.dy;
+
+    const int lrow = tid >> 5, col4 = tid & 31;
+    const int st0 = split * a.stages_per_split;
+    const int st1 = min(a.stages, st0 + a.stages_per_split);
+    float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
+    const int ci = ci0 + col4 * 4;
+    const bool ci_ok = ci < a.Cin;
+    if (XFORM && ci_ok) {
+        sc = *reinterpret_cast<const float4*>(a.in_scale + ci);
+        sh = *reinterpret_cast<const float4*>(a.in_shift + ci);
+    }
+    const int co = co0 + col4 * 4;
+    const bool co_ok = co < a.CoutRow;
+
+    float4 ra[4], rb[4];
+    unsigned amask = 0, bmask = 0;
+    auto load_stage = [&](int st_) {
+        amask = 0; bmask = 0;
+#pragma unroll
+        for (int I = 0; I < 4; ++I) {
+            const int m = st_ * TK + lrow + 8 * I;
+            const bool mok = m < a.M;
+            const int n = fastdiv(m, a.dHoWo);
+            const int rem = m - n * a.HoWo;
+            const int ho = fastdiv(rem, a.dWo), wo = rem - ho * a.Wo;
+            const int hi = ho * a.stride - a.pad + r, wi = wo * a.stride - a.pad + s;
+            const bool aok = mok && co_ok;
+            const bool bok = mok && ci_ok && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi;
+            const size_t aoff = aok ? (size_t)n * a.dy_batch_stride + (size_t)rem * a.CoutRow + co : (size_t)0;
+            const size_t boff = bok ? ((size_t)(n * a.Hi + hi) * a.Wi + wi) * a.Cin + ci : (size_t)0;
+            ra[I] = *reinterpret_cast<const float4*>(dybase + aoff);
+            rb[I] = *reinterpret_cast<const float4*>(xbase + boff);
+            amask |= (aok ? 1u : 0u) << I;
+            bmask |= (bok ? 1u : 0u) << I;
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int I = 0; I < 4; ++I) {
+            float4 va = ra[I], vb = rb[I];
+            if (XFORM) {
+                vb.x = fmaxf(fmaf(vb.x, sc.x, sh.x), 0.f); vb.y = fmaxf(fmaf(vb.y, sc.y, sh.y), 0.f);
+                vb.z = fmaxf(fmaf(vb.z, sc.z, sh.z), 0.f); vb.w = fmaxf(fmaf(vb.w, sc.w, sh.w), 0.f);
+            }
+            if (!((amask >> I) & 1u)) va = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!((bmask >> I) & 1u)) vb = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int row = lrow + 8 * I;
+            const int off = 256 * row + 16 * ((col4 >> 1) ^ (((row & 3) << 2) | ((row >> 2) & 3))) + 8 * (col4 & 1);
+            const wf32x4 fa = {va.x, va.y, va.z, va.w}, fb = {vb.x, vb.y, vb.z, vb.w};
+            *reinterpret_cast<wbf16x4*>(lds + (buf * 2 + 0) * IMG + off) = __builtin_convertvector(fa, wbf16x4);
+            *reinterpret_cast<wbf16x4*>(lds + (buf * 2 + 1) * IMG + off) = __builtin_convertvector(fb, wbf16x4);
+        }
+    };
+
+    // transposed fragment reads: 16-lane group g = lane >> 4 takes pixel rows r0 .. r0 + 3 (r0 = 16 kc + 8 (g >> 1) + 4 jj) and the 16
+    // channels wX * 64 + 32 t + 16 (g & 1) ..; lane 4 q + p of the group supplies row r0 + q, chunk c0 + (p >> 1), byte 8 (p & 1)
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    int fo[2][2][2];      // [operand][tile][jj]: byte offset inside an image for kc = 0 (kc adds 16 rows = 4,096 B: same XOR term)
+#pragma unroll
+    for (int op = 0; op < 2; ++op)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int row = 8 * (g >> 1) + 4 * jj + q;
+                const int ch = (op ? wn : wm) * 8 + 4 * t + 2 * (g & 1) + (pp >> 1);
+                fo[op][t][jj] = 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) + 8 * (pp & 1);
+            }
+    auto frag = [&](int buf, int op, int t, int kc) -> wbf16x8 {
+        const char* base = lds + (buf * 2 + op) * IMG + kc * 4096;
+        const ws16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(base + fo[op][t][0]));
+        const ws16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(base + fo[op][t][1]));
+        return __builtin_bit_cast(wbf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
+
+    if (st0 < st1) {
+        load_stage(st0);
+        store_stage(0);
+        load_stage(st0 + 1 < st1 ? st0 + 1 : st0);
+    }
+    __syncthreads();
+    for (int st = st0; st < st1; ++st) {
+        const int buf = (st - st0) & 1;
+        store_stage(buf ^ 1);                                   // registers hold tile st + 1
+        load_stage(st + 2 < st1 ? st + 2 : st1 - 1);            // in flight during the MFMAs below
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            wbf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { fa[t] = frag(buf, 0, t, kc); fb[t] = frag(buf, 1, t, kc); }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t], fb[u], acc[t][u], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // slab store: ws[split][co][tap][ci]; tile (t, u) element e: co = co0 + wm*64 + 32 t + row, ci = ci0 + wn*64 + 32 u + (lane & 31)
+    float* slab = a.ws + (size_t)split * a.CoutT * a.taps * a.CinT;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            const int cco = co0 + wm * 64 + 32 * t + row;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) slab[((size_t)cco * a.taps + tap) * a.CinT + ci0 + wn * 64 + 32 * u + (lane & 31)] = acc[t][u][e];
+        }
+}
+
 // dw_oihw[co][ci][tap] = sum_split ws[split][co][tap][ci]
 // (Cin = channels of dw's OIHW layout: the padded RGB input has 4 in x but 3 in the parameter)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int taps, int CoutT,
@@ -364,13 +511,17 @@ int ssdhip_conv2d_wgrad(const ssdhip_wgrad_params* p, void* stream) {
     SSDHIP_REQUIRE(p && p->x && p->dy && p->dw_oihw && p->ws, "wgrad: null pointer");
     SSDHIP_REQUIRE(p->Cin % 4 == 0 && p->dy_row % 4 == 0 && p->dy_row >= p->Cout, "wgrad: Cin and dy_row must be multiples of 4");
     SSDHIP_REQUIRE(p->R == p->S && (p->R == 1 || p->R == 3), "wgrad: 1x1 or 3x3 kernels");
+    SSDHIP_REQUIRE(p->compute == 0 || p->compute == 1, "wgrad: compute must be 0 (fp32) or 1 (bf16 operands)");
     SSDHIP_REQUIRE((p->in_scale == nullptr) == (p->in_shift == nullptr), "wgrad: in_scale and in_shift go together");
     SSDHIP_REQUIRE((int64_t)p->N * p->Hi * p->Wi < (1ll << 31), "wgrad: tensor too large");
     WgradArgs a;
     plan(p, a);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(a.CB * a.IB * a.taps * a.splitK), block(256);
-    if (p->in_scale) hipLaunchKernelGGL(wgrad_kernel<true>, grid, block, 0, st, a);
+    if (p->compute == 1) {
+        if (p->in_scale) hipLaunchKernelGGL(wgrad_bf16_kernel<true>, grid, block, 0, st, a);
+        else hipLaunchKernelGGL(wgrad_bf16_kernel<false>, grid, block, 0, st, a);
+    } else if (p->in_scale) hipLaunchKernelGGL(wgrad_kernel<true>, grid, block, 0, st, a);
     else hipLaunchKernelGGL(wgrad_kernel<false>, grid, block, 0, st, a);
     SSDHIP_CHECK_LAUNCH();
     const int dw_cin = p->dw_cin > 0 ? p->dw_cin : p->Cin;

@@ -667,8 +667,9 @@ class Engine:
                 if spec is None or spec.frozen:
                     continue
                 p = self._wgrad_params(spec, N, hi, wi, ho, wo)
-                fn = self.lib.ssdhip_conv2d_wgrad_winograd_ws_bytes if self._wgrad_wino(spec, hi, wi) else self.lib.ssdhip_conv2d_wgrad_ws_bytes
-                ws_bytes = max(ws_bytes, _lib.check(fn(ctypes.byref(p)), 'wgrad_ws_bytes'))
+                ws_bytes = max(ws_bytes, _lib.check(self.lib.ssdhip_conv2d_wgrad_ws_bytes(ctypes.byref(p)), 'wgrad_ws_bytes'))    # direct (bf16 mode: always)
+                if self._wgrad_wino(spec, hi, wi):
+                    ws_bytes = max(ws_bytes, _lib.check(self.lib.ssdhip_conv2d_wgrad_winograd_ws_bytes(ctypes.byref(p)), 'wgrad_ws_bytes'))
         bw['wgrad_ws'] = torch.empty((ws_bytes + 3) // 4, **f)
         dg_v = dg_m = 0             # Winograd data gradients (un-frozen backbone): dy planes V and dx planes M
         for i in range(self.tail_start + 1, len(self.stages)):
@@ -708,7 +709,9 @@ class Engine:
         # reference's autograd holds rounding noise there; the flat buffer slot stays 0 (zeroed at allocation)
         p.dbias = views[prefix + '.bias'].data_ptr() if (spec.is_head and (prefix + '.bias') in views) else None
         p.ws = bw['wgrad_ws'].data_ptr()
-        fn = self.lib.ssdhip_conv2d_wgrad_winograd if self._wgrad_wino(spec, hi, wi) else self.lib.ssdhip_conv2d_wgrad
+        # bf16 mode: operands rounded to bf16 at staging, 16x the matrix rate -- the direct kernel outruns the fp32 Winograd form
+        p.compute = int(self.bf16)
+        fn = self.lib.ssdhip_conv2d_wgrad_winograd if (self._wgrad_wino(spec, hi, wi) and not self.bf16) else self.lib.ssdhip_conv2d_wgrad
         _lib.check(fn(ctypes.byref(p), _lib.stream()), f'wgrad {spec.name}')
 
     def _dgrad_wino(self, spec, g):

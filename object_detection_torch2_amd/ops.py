@@ -219,8 +219,9 @@ def conv2d_dgrad(dy, w_oihw, in_hw, stride=1, pad=0, accumulate_into=None, tile=
     return dx
 
 
-def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, in_scale=None, in_shift=None, want_bias=True, winograd=False):
-    """x (N,Hi,Wi,Cin), dy (N,Ho,Wo,dy_row>=Cout) -> (dW OIHW, db or None).  winograd=True: F(2x2,3x3) path (3x3/s1/p1)."""
+def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, in_scale=None, in_shift=None, want_bias=True, winograd=False, bf16=False):
+    """x (N,Hi,Wi,Cin), dy (N,Ho,Wo,dy_row>=Cout) -> (dW OIHW, db or None).  winograd=True: F(2x2,3x3) path (3x3/s1/p1).
+    bf16 (direct path only): operands rounded to bf16 at staging, bf16 MFMA with fp32 accumulate, fp32 result."""
     _lib.require_gpu(x, dy)
     lib = _lib.load()
     cout, cin, k, _ = w_shape
@@ -236,6 +237,9 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, in_scale=None, in_shift=None, 
     p.dy_batch_stride = ho * wo * row
     p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout = N, hi, wi, cin, ho, wo, cout
     p.R, p.S, p.stride, p.pad, p.dy_row = k, k, stride, pad, row
+    if bf16 and winograd:
+        raise ValueError('conv2d_wgrad: the bf16 weight gradient is the direct kernel (no Winograd form)')
+    p.compute = int(bf16)
     fn_ws, fn = (lib.ssdhip_conv2d_wgrad_winograd_ws_bytes, lib.ssdhip_conv2d_wgrad_winograd) if winograd else \
         (lib.ssdhip_conv2d_wgrad_ws_bytes, lib.ssdhip_conv2d_wgrad)
     ws = torch.empty((_lib.check(fn_ws(ctypes.byref(p)), 'wgrad_ws_bytes') + 3) // 4, device=x.device, dtype=torch.float32)

@@ -65,6 +65,41 @@ def test_conv_dgrad_bf16(case):
     assert rel_err(dx.permute(0, 3, 1, 2).cpu(), x.grad) < 2e-5
 
 
+@pytest.mark.parametrize('case', BWD_CASES + [(32, 19, 19, 512, 1024, 3, 1, 1), (3, 38, 38, 512, 100, 3, 1, 1)])
+def test_conv_wgrad_bf16(case):
+    """Weight gradient with bf16 operands (conv_wgrad.hip wgrad_bf16_kernel: transposed LDS fragment reads) vs autograd on the SAME
+    bf16-rounded operands: exact products, fp32 accumulation -> the fp32 kernel's 2e-5."""
+    from object_detection_torch2_amd import ops
+    N, H, W, cin, cout, k, stride, pad = case
+    x = r16(rnd(N, cin, H, W, seed=11))
+    w = torch.zeros(cout, cin, k, k, requires_grad=True)
+    b = torch.zeros(cout, requires_grad=True)
+    y = F.conv2d(x, w, b, stride=stride, padding=pad)
+    dy = r16(rnd(*y.shape, seed=13))
+    y.backward(dy)
+    cpad = (cout + 31) // 32 * 32
+    dw, db = ops.conv2d_wgrad(ops.to_nhwc(x.to(DEV)), ops.to_nhwc(dy.to(DEV), pad_to=cpad), tuple(w.shape), stride=stride, pad=pad, bf16=True)
+    assert rel_err(dw.cpu(), w.grad) < 2e-5
+    assert rel_err(db.cpu(), b.grad) < 2e-5
+
+
+def test_conv_wgrad_bf16_fused_input_transform():
+    """BN.ReLU of the producer in fp32 BEFORE the rounding of the activation to bf16 (as in the forward)."""
+    from object_detection_torch2_amd import ops
+    N, H, W, cin, cout = 2, 10, 10, 128, 128
+    zprev = rnd(N, cin, H, W, seed=14)
+    scale, shift = rnd(cin, seed=15), rnd(cin, seed=16)
+    a = r16(F.relu(zprev * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)))
+    w = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    dy = r16(rnd(N, cout, H, W, seed=18))
+    F.conv2d(a, w, None, padding=1).backward(dy)
+    dw, _ = ops.conv2d_wgrad(ops.to_nhwc(zprev.to(DEV)), ops.to_nhwc(dy.to(DEV)), tuple(w.shape), pad=1, in_scale=scale.to(DEV),
+                             in_shift=shift.to(DEV), want_bias=False, bf16=True)
+    assert rel_err(dw.cpu(), w.grad) < 2e-4           # a value on a rounding boundary may round the other way after the fma
+    with pytest.raises(ValueError):
+        ops.conv2d_wgrad(ops.to_nhwc(zprev.to(DEV)), ops.to_nhwc(dy.to(DEV)), tuple(w.shape), pad=1, winograd=True, bf16=True)
+
+
 def test_model_bf16_forward_and_training_close_to_fp32(golden):
     """Whole path in bf16 compute mode against the fp32 references: forward within bf16 noise of the oracle, the 3-step
     training trajectory within 2 % of the golden fp32 losses, fp32 mode restored bit-for-bit afterwards."""
