@@ -414,12 +414,15 @@ def main():
         if args.imsize != 300:      # extension variant, never the headline: say so in every field a reader may look at
             P = net.topo.num_priors()
             line['metric'] = f'images/sec SSD{args.imsize} {"train step" if args.mode == "train" else "inference"}, batch {B}/GPU (extension variant, not the BASELINE metric)'
-            line['config'].update(workload=f'SSD{args.imsize} {args.mode} batch={B}/GPU, fp32 ({P} priors; BASELINE configs[4] names its bf16 8-GPU form)',
+            line['config'].update(workload=f'SSD{args.imsize} {args.mode} batch={B}/GPU, {args.dtype} ({P} priors; BASELINE configs[4] names its bf16 8-GPU form)',
                                   image=f'{args.imsize}x{args.imsize}x3', priors=P, gflop_per_image=round(gf_train if args.mode == 'train' else gf_fwd, 3))
         if args.dtype == 'bf16':
             line['dtype'] = 'bf16'
+            line['config']['workload'] = line['config']['workload'].replace(', fp32,', ', bf16 fwd/bwd + fp32 master,').replace('BASELINE configs[2]', 'BASELINE configs[3] on one GPU')
             line['metric'] += ' (bf16 MFMA compute with fp32 accumulate / fp32 master state: BASELINE configs[3] form, not the fp32 headline)'
-            line['config']['precision'] = 'conv forward + data gradients: bf16 operands, fp32 accumulate; weights, activations in HBM, BN, weight gradients, loss, Adam: fp32'
+            line['config']['precision'] = ('frozen backbone: bf16 activations in HBM (zero-haloed), bf16 patch convolution with fp32 accumulate; trainable tail: '
+                                           'conv forward, data and weight gradients with bf16 operands (rounded at LDS staging) and fp32 accumulate; '
+                                           'master weights, BN statistics, gradients in HBM, loss, Adam: fp32')
         if args.finetune_backbone:
             line['metric'] += ' (extension: backbone un-frozen, not the BASELINE metric)'
             line['config'].update(backbone='VGG16-bn un-frozen (full fine-tuning)', gflop_per_image=round(gf_train, 3))
