@@ -77,6 +77,7 @@ struct WfArgs {
     float* stats;
     int H, W, C, Cout, KT, NB, MB;
     unsigned x_bytes;
+    int band;         // 1 = an XCD walks a contiguous band of tile blocks (see the kernel), 0 = tile blocks dealt round-robin over the XCDs
     int skew;         // start delay per group of 8 blocks, in units of 1,024 cycles (0 = none): see the kernel
 };
 
@@ -167,21 +168,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // Which blocks share a tile block is a speed matter only: with the round-robin XCD placement (block b on XCD b % 8) the NB
     // blocks of one tile block are given ids that differ by 8, i.e. one XCD, so the input strips they all fetch at the same time
     // miss that XCD's L2 once instead of NB times (measured fabric traffic was 3x the algorithmic bytes without it).
-    const int G = gridDim.x, mbstep = G / a.NB;
-    int nb, mb0;
+    const int G = gridDim.x;
+    int nb, mb0, mbstep = G / a.NB, mb_end = a.MB;
     if (G % (8 * a.NB) == 0) {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         nb = slot % a.NB;
-        mb0 = (slot / a.NB) * 8 + xcd;
+        if (a.band) {
+            // each XCD walks its own contiguous eighth of the tile blocks, its groups side by side: the tile rows that re-read a strip
+            // (rows of tiles overlap by two pixel rows) run on the same XCD at about the same time and find the strip in its L2
+            const int L = (a.MB + 7) >> 3;
+            mbstep = (G >> 3) / a.NB;
+            mb0 = xcd * L + slot / a.NB;
+            mb_end = min(a.MB, (xcd + 1) * L);
+        } else {
+            mb0 = (slot / a.NB) * 8 + xcd;
+        }
     } else {
         nb = blockIdx.x % a.NB;
         mb0 = blockIdx.x / a.NB;
     }
-    if (mb0 >= a.MB) return;                 // fewer tile blocks than groups (whole block: uniform)
-    // Equal items keep 256 persistent blocks in lockstep: every CU stores its 64 KiB of output (and issues its strip DMAs) in the
-    // same microsecond and HBM sees bursts with idle time between them.  A start delay that grows with the block id spreads them.
+    if (mb0 >= mb_end) return;               // fewer tile blocks than groups (whole block: uniform)
+    // probe knob: a start delay that grows with the block id (to break the lockstep of equal items); see the host side
     for (int k = (int)(blockIdx.x >> 3) * a.skew; k > 0; --k) __builtin_amdgcn_s_sleep(16);
-    const int cnt = (a.MB - mb0 + mbstep - 1) / mbstep;
+    const int cnt = (mb_end - mb0 + mbstep - 1) / mbstep;
     const int n0 = nb * WF_COUT;
     const int KT = (ABL & 16) ? 4 : a.KT;
 
@@ -520,11 +529,13 @@ int ssdhip_wino_fused_conv(const float* x, const float* upk, const float* bias, 
     a.MB = ssdhip_wino_fused_stat_rows(N, H, W);
     SSDHIP_REQUIRE(a.MB > 0 && a.NB <= 256, "wino_fused_conv: bad shape");
     a.x_bytes = (unsigned)((int64_t)N * H * W * Cin * 4);
-    // measured (scripts/wf_bench.py, SKEWS=...): conv_1_2 (8 K-steps per 64 KiB of output) 1.48 -> 1.29 ms with 2; layers with longer
-    // K loops or two channel tiles lose 1-2 % to the longer tail instead
-    a.skew = (a.KT <= 8 && a.NB == 1) ? 2 : 0;
+    // start skew: measured neutral to slightly negative once the device is warm (scripts/wf_bench.py SKEWS=0,2,0,2: conv_1_2 1.275 vs
+    // 1.294 ms); kept as a probe-build knob only
+    a.skew = 0;
+    a.band = 1;
 #ifdef SSDHIP_PROBES
     if (const char* e = getenv("SSDHIP_WF_SKEW")) a.skew = atoi(e);
+    if (const char* e = getenv("SSDHIP_WF_BAND")) a.band = atoi(e);
 #endif
     // persistent grid: one block per CU, a multiple of NB so that a block keeps its channel tile (and its weight slice in L2)
     const int64_t items = (int64_t)a.MB * a.NB;

@@ -10,7 +10,9 @@ L = [('conv_1_2', 300, 64, 64), ('conv_2_1', 150, 64, 128), ('conv_2_2', 150, 12
      ('conv_4_1', 38, 256, 512), ('conv_4_2', 38, 512, 512), ('conv_5_1', 19, 512, 512)]
 only = os.environ.get('LAYERS')
 def timeit(fn, reps=6):
-    fn(); torch.cuda.synchronize()
+    for _ in range(4):
+        fn()
+    torch.cuda.synchronize()
     ts = []
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -11,7 +11,9 @@ L = [('conv_1_2', 300, 64, 64), ('conv_2_1', 150, 64, 128), ('conv_2_2', 150, 12
 only = os.environ.get('LAYERS')
 torch.manual_seed(0)
 def timeit(fn, reps=6):
-    fn(); torch.cuda.synchronize()
+    for _ in range(4):       # the first launches of a process run slower (clock ramp): an A/B measured first loses by 10 %
+        fn()
+    torch.cuda.synchronize()
     ts = []
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -34,6 +36,11 @@ for name, H, cin, cout in L:
         ba, ma = timeit(lambda: ops.wino_fused_conv(x, w, b, in_scale=sc, in_shift=sh, want_stats=True, upk=upk))
         del os.environ['SSDHIP_WF_SKEW']
         print(f'    skew {sk}: min {ba:7.3f} med {ma:7.3f} ms ({wino / ma / 1e9:6.1f} TF executed)', flush=True)
+    for bd in [int(v) for v in os.environ.get('BANDS', '').split(',') if v]:
+        os.environ['SSDHIP_WF_BAND'] = str(bd)
+        ba, ma = timeit(lambda: ops.wino_fused_conv(x, w, b, in_scale=sc, in_shift=sh, want_stats=True, upk=upk))
+        del os.environ['SSDHIP_WF_BAND']
+        print(f'    band {bd}: min {ba:7.3f} med {ma:7.3f} ms ({wino / ma / 1e9:6.1f} TF executed)', flush=True)
     for abl in [int(v) for v in os.environ.get('ABLS', '').split(',') if v]:
         os.environ['SSDHIP_WF_ABL'] = str(abl)
         ba, ma = timeit(lambda: ops.wino_fused_conv(x, w, b, in_scale=sc, in_shift=sh, want_stats=True, upk=upk))
