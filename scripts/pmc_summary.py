@@ -6,8 +6,8 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = collections.defaultdict(dict)
 def short(n):
     return n.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
-for tag in ('fetch', 'write', 'sq'):
-    files = glob.glob(os.path.join(root, 'gpurun_out', f'pmc_{tag}', '*', '*_counter_collection.csv'))
+for tag, suffix in [(t, sfx) for sfx in ('', '_bf16') for t in ('fetch', 'write', 'sq')]:
+    files = glob.glob(os.path.join(root, 'gpurun_out', f'pmc_{tag}{suffix}', '*', '*_counter_collection.csv'))
     if not files:
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -15,6 +15,10 @@ for tag in ('fetch', 'write', 'sq'):
     for r in csv.DictReader(open(files[-1])):
         agg[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
     for k, cs in agg.items():
+        if suffix and ('launches_' + tag) in out.get(k, {}) and not out[k].get('from' + suffix):
+            continue                    # a kernel of the fp32 headline run keeps the headline run's counters
+        if suffix:
+            out[k]['from' + suffix] = 1
         for c, v in cs.items():
             out[k][c] = sum(v) / len(v)
             out[k]['launches_' + tag] = len(v)
