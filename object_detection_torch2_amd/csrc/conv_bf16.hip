@@ -144,19 +144,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)lds;
 
     // work items (tile block mb, channel tile nb): a block keeps nb (the host makes the grid a multiple of NB) and walks
-    // mb0, mb0 + mbstep, ...; blocks that share a tile block get ids 8 apart = one XCD (round-robin placement), see wino_fused.hip
-    const int G = gridDim.x, mbstep = G / a.NB;
-    int nb, mb0;
+    // mb0, mb0 + mbstep, ... below mb_end
+    const int G = gridDim.x;
+    int nb, mb0, mbstep = G / a.NB, mb_end = a.MB;
     if (G % (8 * a.NB) == 0) {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        // an XCD walks a contiguous eighth of the tile blocks, its groups side by side: neighbouring patches (shared halo rows) and
+        // the channel tiles of one patch meet in one L2 (wino_fused.hip: halved that kernel's fabric traffic)
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, L = (a.MB + 7) >> 3;
         nb = slot % a.NB;
-        mb0 = (slot / a.NB) * 8 + xcd;
+        mbstep = (G >> 3) / a.NB;
+        mb0 = xcd * L + slot / a.NB;
+        mb_end = min(a.MB, (xcd + 1) * L);
     } else {
         nb = blockIdx.x % a.NB;
         mb0 = blockIdx.x / a.NB;
     }
-    if (mb0 >= a.MB) return;
-    const int cnt = (a.MB - mb0 + mbstep - 1) / mbstep;
+    if (mb0 >= mb_end) return;
+    const int cnt = (mb_end - mb0 + mbstep - 1) / mbstep;
     for (int k = (int)(blockIdx.x >> 3) * a.skew; k > 0; --k) __builtin_amdgcn_s_sleep(16);
     const int n0 = nb * BN;
     const int steps = a.KCB * 9;
