@@ -77,8 +77,12 @@ typedef struct {
     int64_t w_img_stride;   /* floats between consecutive weight planes (with rows_per_img)      */
     int32_t compute;        /* 0: exact fp32 MFMA (default, the headline path); 1: operands rounded to bf16 at LDS staging,
                                v_mfma_f32_32x32x16_bf16 with fp32 accumulate (BASELINE configs[3]); tensors stay fp32 in HBM */
+    float* ws;              /* NULL, or split-K workspace of ws_bytes bytes (ssdhip_conv2d_ws_bytes): launches whose tile grid cannot
+                               fill the chip (tiny maps) split K over blocks and sum the partial tiles in a second, fixed-order pass */
+    int64_t ws_bytes;
 } ssdhip_conv_params;
 int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream);
+int64_t ssdhip_conv2d_ws_bytes(const ssdhip_conv_params* p);   /* split-K workspace this launch can use (0 = it does not split) */
 /* m-block size the auto/explicit tile choice will use for `stats` (rows of the partial table = ceil(M/BM)) */
 int ssdhip_conv2d_block_m(const ssdhip_conv_params* p);
 /* BM*1000+BN the call will run with (profiling / bench bookkeeping) */

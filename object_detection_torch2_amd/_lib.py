@@ -26,7 +26,7 @@ class ConvParams(Structure):
                 ('Ho', c_int32), ('Wo', c_int32), ('Cout', c_int32),
                 ('R', c_int32), ('S', c_int32), ('stride', c_int32), ('pad', c_int32),
                 ('KP', c_int32), ('mode', c_int32), ('accumulate', c_int32), ('tile', c_int32),
-                ('rows_per_img', c_int32), ('w_img_stride', c_int64), ('compute', c_int32)]
+                ('rows_per_img', c_int32), ('w_img_stride', c_int64), ('compute', c_int32), ('ws', c_void_p), ('ws_bytes', c_int64)]
 
 
 class WgradParams(Structure):
@@ -46,6 +46,7 @@ SIGNATURES = {
     'ssdhip_pack_conv_weight': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ssdhip_conv2d_nhwc': (c_int, [POINTER(ConvParams), c_void_p]),
     'ssdhip_conv2d_block_m': (c_int, [POINTER(ConvParams)]),
+    'ssdhip_conv2d_ws_bytes': (c_int64, [POINTER(ConvParams)]),
     'ssdhip_conv2d_tile': (c_int, [POINTER(ConvParams)]),
     'ssdhip_winograd_tiles': (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     'ssdhip_winograd_weight': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

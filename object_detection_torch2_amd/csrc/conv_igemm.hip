@@ -63,6 +63,12 @@ struct ConvArgs {
     // persistent plane-GEMM blocks: each block walks tpb consecutive m-tiles of one n-tile as ONE software pipeline (the loads
     // of the next tile's first K-steps are in flight during the current tile's last MFMAs and its stores); 1 = one tile per block
     int tpb;
+    // split-K for launches whose tile grid cannot fill the chip (the 10x10 .. 1x1 maps of the tail: a few blocks walking 36-144
+    // K-steps each, one exposed load latency per step): block z = blockIdx.x / tiles walks K-steps [z * kt_per, (z + 1) * kt_per) and
+    // stores its raw accumulators to slab z; conv_splitk_reduce_kernel sums the slabs in fixed order and does the epilogue
+    // (bias, accumulate, strided store, BatchNorm partial sums).  ksplit == 1: off.
+    int ksplit, kt_per;
+    float* slab;
 };
 
 template <int KS>
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWave
     // XCD-aware bijective tile order (blocks b, b+8, ... share an XCD)
     int t;
     {
-        const int T = ((a.MB + a.tpb - 1) / a.tpb) * a.NB, bid = blockIdx.x;
+        const int T = ((a.MB + a.tpb - 1) / a.tpb) * a.NB, bid = a.ksplit > 1 ? (int)(blockIdx.x % (unsigned)T) : (int)blockIdx.x;
         const int xcd = bid & 7, local = bid >> 3, q = T >> 3, r = T & 7;
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
     }
@@ -101,6 +107,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWave
     const int mt_idx = mchunk * a.tpb;                         // first m-tile of this block
     const int ntl = min(a.tpb, a.MB - mt_idx);                 // m-tiles this block walks
     const int m0 = mt_idx * BM, n0 = nt_idx * BN;
+    const int split = a.ksplit > 1 ? (int)(blockIdx.x / (unsigned)(a.MB * a.NB)) : 0;
+    const int kt_lo = split * a.kt_per, kt_hi = a.ksplit > 1 ? min(a.KT, kt_lo + a.kt_per) : a.KT;      // this block's K-steps
 
     // ---- per-thread gather state: AL rows of the A tile, fixed 16-B column slot --------------------------------
     // 32-bit BYTE offsets against uniform base pointers (global_load saddr + voffset form, no 64-bit VALU math)
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWave
     // OUTER, tap INNER, so the 9 taps re-read each 128-B input line in 9 consecutive K-steps (L1/L2 hits; with the tap outer
     // the re-reads were a whole K loop apart and the per-XCD L2 thrashed: 3.3x the algorithmic bytes at the fabric counters).
     // SMALLC (Cin == 4, padded RGB): a stage is 8 taps x 4 channels, k = tap * 4 + c.
-    int ld_kt = 0, ld_tap = 0, ld_cc = 0;
+    int ld_kt = kt_lo, ld_cc = SMALLC ? 0 : kt_lo / (a.nr * a.ns), ld_tap = SMALLC ? 0 : kt_lo - ld_cc * (a.nr * a.ns);
     int tap, r, s, c;
     unsigned tapoff, woff_k;
 #define CONV_PREP()                                                                                                   \
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWave
             sh = *reinterpret_cast<const float4*>(a.in_shift + c);                                                    \
         }                                                                                                             \
         okmask = 0;                                                                                                   \
-        if (ld_kt < a.KT - 1) {    /* channel block outer, tap inner: the 9 taps of one 128-B line are consecutive */ \
+        if (ld_kt < kt_hi - 1) {   /* channel block outer, tap inner: the 9 taps of one 128-B line are consecutive */ \
             ++ld_kt;                                                                                                  \
             if (++ld_tap == a.nr * a.ns) { ld_tap = 0; ++ld_cc; }                                                     \
         } else if (ld_tile + 1 < ntl) { ld_kt = 0; ld_tap = 0; ld_cc = 0; ld_wrap = true; }                           \
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWave
     const float* Afr = As + (wm * WROWS + frow) * LROW;
     const float* Bfr = Bs + (wn * WCOLS + frow) * LROW;
     const int fko8[2] = {((0 + fh) ^ ((frow >> 2) & 3)) * 4, ((2 + fh) ^ ((frow >> 2) & 3)) * 4};   // bf16: chunk 2 m + fh of MFMA m
-    const int total_steps = ntl * a.KT;
+    const int total_steps = ntl * (kt_hi - kt_lo);
     int kt_in = 0, m_cur = m0;             // K-step inside the current m-tile, first row of that tile
     for (int kt = 0; kt < total_steps; ++kt) {
         const int buf = kt & 1;
@@ -351,6 +359,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWave
     // ---- epilogue ------------------------------------------------------------------------------------------------
     // C/D map of the 32x32 tile: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
     const int ccol = lane & 31, rquad = 4 * (lane >> 5);
+    if (a.ksplit > 1) {            // raw partial sums -> slab[split][m][co]; the reduce kernel does the rest
+        float* slab = a.slab + (size_t)split * a.M * a.Cout;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int co = n0 + wn * WCOLS + j * 32 + ccol;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + wm * WROWS + i * 32 + (e & 3) + 8 * (e >> 2) + rquad;
+                    if (m < a.M && co < a.Cout) slab[(size_t)m * a.Cout + co] = acc[i][j][e];
+                }
+        }
+        return;
+    }
     float s1[NT], s2[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -408,6 +431,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, ConvWave
     }
 }
 
+// Second pass of a split-K launch: y = sum over slabs (fixed order) + bias with the epilogue's addressing (dense / strided /
+// accumulate) and its BatchNorm partial sums per BM-row block.  grid (MB, ceil(Cout / 64)), 1,024 threads = 64 channels x 16 row
+// lanes: a thread owns BM / 16 rows and has all their slab values in flight at once (the pass is a latency chain otherwise).
+__global__ __launch_bounds__(1024) void conv_splitk_reduce_kernel(ConvArgs a, int BM) {
+    __shared__ float red[16][64][2];
+    const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int co = blockIdx.y * 64 + col;
+    const bool cok = co < a.Cout;
+    const int mb = blockIdx.x, m_lo = mb * BM, m_hi = min(a.M, m_lo + BM);
+    const float bv = (a.bias != nullptr && cok) ? a.bias[co] : 0.f;
+    const size_t slab_stride = (size_t)a.M * a.Cout;
+    float t1 = 0.f, t2 = 0.f;
+    if (cok) {
+        for (int m = m_lo + rl; m < m_hi; m += 16) {
+            const float* sp = a.slab + (size_t)m * a.Cout + co;
+            float part[8];
+#pragma unroll
+            for (int z = 0; z < 8; ++z) part[z] = z < a.ksplit ? sp[z * slab_stride] : 0.f;
+            float v = part[0];
+#pragma unroll
+            for (int z = 1; z < 8; ++z) v += part[z];          // fixed order; the unused slots add +0
+            v += bv;
+            float* dst;
+            if (a.dense) dst = a.y + (size_t)m * a.Cout + co;
+            else {
+                const int n = m / a.HoWo;
+                const int rem = m - n * a.HoWo;
+                const int hh = rem / a.Wo, ww = rem - hh * a.Wo;
+                dst = a.y + (size_t)n * a.y_batch_stride + (size_t)((a.oh0 + a.ostep * hh) * a.OWf + a.ow0 + a.ostep * ww) * a.Cout + co;
+            }
+            if (a.accumulate) v += *dst;
+            *dst = v;
+            t1 += v;
+            t2 += v * v;
+        }
+    }
+    if (a.stats != nullptr) {
+        red[rl][col][0] = t1; red[rl][col][1] = t2;
+        __syncthreads();
+        if (rl == 0 && cok) {
+            float2 o = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { o.x += red[k][col][0]; o.y += red[k][col][1]; }
+            *reinterpret_cast<float2*>(a.stats + ((size_t)mb * a.Cout + co) * 2) = o;
+        }
+    }
+}
+
+// launches whose tile grid is this small are latency chains of K-steps: split K over blocks (plan_split)
+static int plan_split(int MB, int NB, int KT, int64_t M, int Cout, int64_t ws_bytes, int& kt_per) {
+    kt_per = KT;
+    const int blocks = MB * NB;
+    if (blocks > 192 || KT < 8) return 1;
+    int ks = 384 / blocks;            // aim at ~1.5 blocks per CU
+    if (ks > 8) ks = 8;
+    if (ks > KT / 2) ks = KT / 2;
+    while (ks > 1 && (int64_t)ks * M * Cout * 4 > ws_bytes) --ks;
+    if (ks < 2) return 1;
+    kt_per = (KT + ks - 1) / ks;
+    return (KT + kt_per - 1) / kt_per;
+}
+
 // OIHW -> packed rows.  mode 0: row = co, inner = ci;  mode 1: row = ci, inner = co.  k order as the loader walks it.
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cout, int Cin, int R, int S,
                                    int rows_pad, int inner_pad, int KP, int mode) {
@@ -450,7 +535,7 @@ int choose_tile(const ssdhip_conv_params* p, int& BM, int& BN) {
 
 template <int BM, int BN, int KS>
 void launch_conv(const ConvArgs& a, int mode, bool xform, bool bf16, hipStream_t st) {
-    dim3 grid(cdiv(a.MB, a.tpb) * a.NB), block(256);
+    dim3 grid(cdiv(a.MB, a.tpb) * a.NB * a.ksplit), block(256);
     if (bf16) {          // never the padded-RGB layer, never a plane GEMM (checked by the caller)
         if (mode == 0) {
             if (xform) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, KS, 0, true, false, 0, true>), grid, block, 0, st, a);
@@ -523,6 +608,7 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
     a.dense = p->y_batch_stride == (int64_t)p->Ho * p->Wo * p->Cout;
     a.w_img_stride = p->w_img_stride; a.rows_per_img = p->rows_per_img;
     a.tpb = 1;
+    a.ksplit = 1; a.kt_per = a.KT; a.slab = p->ws;
     if (p->rows_per_img > 0 && !p->bias && !p->stats && !p->accumulate && p->R == 1 && !p->in_scale && a.M % BM == 0 &&
         p->y_batch_stride == (int64_t)p->Ho * p->Wo * p->Cout) {
         // short-K plane GEMMs: amortise pipeline fill/drain over several m-tiles, but keep >= ~6 blocks per CU
@@ -580,6 +666,7 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
             a.KT = a.cpt * a.nr * a.ns;
             a.MB = cdiv(a.M, BM);
         }
+        a.ksplit = (p->ws && p->Cin != 4 && p->rows_per_img == 0 && a.tpb == 1) ? plan_split(a.MB, a.NB, a.KT, a.M, a.Cout, p->ws_bytes, a.kt_per) : 1;
         switch (key) {
             SSDHIP_CONV_CASE(128, 128)
             SSDHIP_CONV_CASE(128, 64)
@@ -588,9 +675,24 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
             default: ssdhip_set_error("conv2d: unsupported tile"); return SSDHIP_ENOSUP;
         }
         SSDHIP_CHECK_LAUNCH();
+        if (a.ksplit > 1) {
+            hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(a.MB, cdiv(a.Cout, 64)), dim3(1024), 0, st, a, BM);
+            SSDHIP_CHECK_LAUNCH();
+        }
     }
 #undef SSDHIP_CONV_CASE
     return SSDHIP_OK;
+}
+
+int64_t ssdhip_conv2d_ws_bytes(const ssdhip_conv_params* p) {
+    // bytes of split-K workspace this launch can use (0: the launch does not split).  Sized for the largest split plan_split picks.
+    int BM, BN;
+    if (!p || choose_tile(p, BM, BN) != SSDHIP_OK || p->Cin == 4 || p->rows_per_img != 0 || p->KP <= 0) return 0;
+    const int64_t M = (int64_t)p->N * p->Ho * p->Wo;
+    if (p->mode == 1 && p->stride == 2 && p->R == 3 && M >= 8192) return 0;       // parity-class launches: large grids
+    int kt_per;
+    const int ks = plan_split(cdiv(M, BM), cdiv(p->Cout, BN), p->KP / BK, M, p->Cout, (int64_t)1 << 40, kt_per);
+    return ks > 1 ? (int64_t)ks * M * p->Cout * 4 : 0;
 }
 
 int ssdhip_pack_conv_weight(const float* w_oihw, float* packed, int Cout, int Cin, int R, int S, int rows_pad, int inner_pad,

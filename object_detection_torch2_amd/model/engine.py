@@ -340,6 +340,7 @@ class Engine:
         p.R, p.S, p.stride, p.pad = spec.k, spec.k, spec.stride, spec.pad
         p.KP, p.mode, p.accumulate, p.tile = spec.KP, 0, 0, tile
         p.compute = int(self.bf16 and spec.cin_pad != 4)      # the padded-RGB layer (K = 27) stays on the fp32 kernel
+        self._splitk_ws(spec, p, ('fwd', N, hi, wi))
         bm = self.lib.ssdhip_conv2d_block_m(ctypes.byref(p))
         # roofline leg of bench.py: only launches of >= 10 GFLOP are bracketed (the dominant kernel is among them; an event pair
         # costs a few microseconds of stream time, which the ~40 small launches of the tail would pay for nothing)
@@ -359,6 +360,21 @@ class Engine:
         self.prof.append(dict(layer=spec.name, kernel=kernel, flops=2.0 * N * ho * wo * spec.cout * spec.cin * spec.k * spec.k,
                               e0=e0, e1=e1))
         return bm
+
+    def _splitk_ws(self, spec, p, tag):
+        """Split-K workspace of one (layer, direction): launches on the tiny maps split K over blocks (conv_igemm.hip).  One buffer
+        per layer and direction, because heads, tail convolutions and data gradients of different layers run on different streams."""
+        if os.environ.get('SSD_NO_SPLITK') == '1':
+            return
+        need = self.lib.ssdhip_conv2d_ws_bytes(ctypes.byref(p))
+        if need <= 0:
+            return
+        bufs = spec.__dict__.setdefault('splitk_ws', {})
+        buf = bufs.get(tag)
+        if buf is None or buf.numel() * 4 < need or buf.device.index != torch.cuda.current_device():
+            buf = torch.empty((need + 3) // 4, device=torch.device('cuda', torch.cuda.current_device()), dtype=torch.float32)
+            bufs[tag] = buf
+        p.ws, p.ws_bytes = buf.data_ptr(), buf.numel() * 4
 
     # ------------------------------------------------------------------------------------------------ streams
     def _note_reader(self, stage, event):
@@ -757,6 +773,7 @@ class Engine:
         p.R, p.S, p.stride, p.pad = spec.k, spec.k, spec.stride, spec.pad
         p.KP, p.mode, p.accumulate, p.tile = spec.KPd, 1, int(accumulate), 0
         p.compute = int(self.bf16)
+        self._splitk_ws(spec, p, ('dgrad', N, hdy, wdy))
         _lib.check(self.lib.ssdhip_conv2d_nhwc(ctypes.byref(p), _lib.stream()), f'dgrad {spec.name}')
 
     def backward(self, grad_out):

@@ -29,9 +29,20 @@ def pack_weight(w_oihw, mode=0):
     return packed, KP, inner
 
 
-def conv2d_nhwc(x, w_oihw, bias=None, stride=1, pad=0, in_scale=None, in_shift=None, want_stats=False, tile=0, bf16=False):
+def _splitk_ws(lib, p, split_k):
+    """Workspace for the split-K form of small launches (tiny maps); the returned tensor must outlive the launch."""
+    need = lib.ssdhip_conv2d_ws_bytes(ctypes.byref(p)) if split_k else 0
+    if need <= 0:
+        return None
+    ws = torch.empty((need + 3) // 4, device=torch.device('cuda', torch.cuda.current_device()), dtype=torch.float32)
+    p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
+    return ws
+
+
+def conv2d_nhwc(x, w_oihw, bias=None, stride=1, pad=0, in_scale=None, in_shift=None, want_stats=False, tile=0, bf16=False, split_k=True):
     """x (N,H,W,Cin_pad) fp32 NHWC -> (z (N,Ho,Wo,Cout), stats or None).  stats: (MB, Cout, 2) partial sums.
-    bf16: operands rounded to bf16 at staging, bf16 MFMA with fp32 accumulate (tensors stay fp32)."""
+    bf16: operands rounded to bf16 at staging, bf16 MFMA with fp32 accumulate (tensors stay fp32).  split_k: let launches whose
+    tile grid cannot fill the chip split K over blocks (fixed-order second pass; same result up to the summation order)."""
     _lib.require_gpu(x, w_oihw)
     lib = _lib.load()
     N, H, W, C = x.shape
@@ -54,6 +65,7 @@ def conv2d_nhwc(x, w_oihw, bias=None, stride=1, pad=0, in_scale=None, in_shift=N
         bm = lib.ssdhip_conv2d_block_m(ctypes.byref(p))
         stats = torch.empty((N * ho * wo + bm - 1) // bm, cout, 2, device=x.device, dtype=torch.float32)
         p.stats = stats.data_ptr()
+    ws = _splitk_ws(lib, p, split_k)
     _lib.check(lib.ssdhip_conv2d_nhwc(ctypes.byref(p), _lib.stream()), 'conv2d_nhwc')
     return z, stats
 
@@ -200,7 +212,7 @@ def bn_relu_to_bf16(z, scale, shift, pool_pad=None):
     return buf, view
 
 
-def conv2d_dgrad(dy, w_oihw, in_hw, stride=1, pad=0, accumulate_into=None, tile=0, bf16=False):
+def conv2d_dgrad(dy, w_oihw, in_hw, stride=1, pad=0, accumulate_into=None, tile=0, bf16=False, split_k=True):
     """dy (N,Ho,Wo,Cout_pad) -> dx (N,Hi,Wi,Cin): data gradient of conv2d(x, w, stride, pad)."""
     _lib.require_gpu(dy, w_oihw)
     N, ho, wo, cdy = dy.shape
@@ -215,6 +227,7 @@ def conv2d_dgrad(dy, w_oihw, in_hw, stride=1, pad=0, accumulate_into=None, tile=
     p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout = N, ho, wo, cdy, hi, wi, cin
     p.R, p.S, p.stride, p.pad, p.KP, p.mode, p.accumulate, p.tile = k, k, stride, pad, KP, 1, int(accumulate_into is not None), tile
     p.compute = int(bool(bf16))
+    ws = _splitk_ws(_lib.load(), p, split_k)
     _lib.check(_lib.load().ssdhip_conv2d_nhwc(ctypes.byref(p), _lib.stream()), 'conv2d_dgrad')
     return dx
 

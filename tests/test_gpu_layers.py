@@ -38,6 +38,38 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize('case', [(32, 5, 5, 256, 256, 3, 1, 0), (32, 10, 10, 256, 512, 3, 2, 1), (32, 3, 3, 128, 256, 3, 1, 0), (32, 1, 1, 256, 128, 1, 1, 0),
+                                  (32, 5, 5, 256, 150, 3, 1, 1)])
+def test_conv_split_k_matches_single_pass(case):
+    """Launches on the tiny tail maps split K over blocks (slabs + fixed-order second pass that also does bias, BatchNorm partial
+    sums and the data gradient's accumulate): same values as the single-pass launch up to the summation order, forward and dgrad."""
+    from object_detection_torch2_amd import ops, _lib
+    N, H, W, cin, cout, k, stride, pad = case
+    x = ops.to_nhwc(rnd(N, cin, H, W, seed=61).to(DEV))
+    w = rnd(cout, cin, k, k, seed=62, scale=0.05).to(DEV)
+    b = rnd(cout, seed=63).to(DEV)
+    sc, sh = (rnd(cin, seed=64) * 0.2 + 1).to(DEV), (rnd(cin, seed=65) * 0.1).to(DEV)
+    z1, st1 = ops.conv2d_nhwc(x, w, b, stride=stride, pad=pad, in_scale=sc, in_shift=sh, want_stats=True, split_k=False)
+    z2, st2 = ops.conv2d_nhwc(x, w, b, stride=stride, pad=pad, in_scale=sc, in_shift=sh, want_stats=True, split_k=True)
+    p = _lib.ConvParams()              # the split form really ran: the library reports a workspace for this shape
+    p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout, p.R, p.S, p.stride, p.pad = N, H, W, cin, z1.shape[1], z1.shape[2], cout, k, k, stride, pad
+    p.KP = (k * k * cin + 31) // 32 * 32
+    assert _lib.load().ssdhip_conv2d_ws_bytes(p) > 0
+    scale = z1.abs().max().item()
+    assert (z1 - z2).abs().max().item() < 2e-6 * scale
+    assert st1.shape == st2.shape and torch.allclose(st1.sum(0), st2.sum(0), rtol=1e-5, atol=1e-4 * scale)
+    z3, _ = ops.conv2d_nhwc(x, w, b, stride=stride, pad=pad, in_scale=sc, in_shift=sh, bf16=True, split_k=False)
+    z4, _ = ops.conv2d_nhwc(x, w, b, stride=stride, pad=pad, in_scale=sc, in_shift=sh, bf16=True, split_k=True)
+    assert (z3 - z4).abs().max().item() < 2e-6 * scale
+    cpad = (cout + 31) // 32 * 32
+    dy = ops.to_nhwc(rnd(N, cout, z1.shape[1], z1.shape[2], seed=66).to(DEV), pad_to=cpad)
+    d1 = ops.conv2d_dgrad(dy, w, (H, W), stride=stride, pad=pad, split_k=False)
+    d2 = ops.conv2d_dgrad(dy, w, (H, W), stride=stride, pad=pad, split_k=True)
+    assert (d1 - d2).abs().max().item() < 2e-6 * d1.abs().max().item()
+    d3 = ops.conv2d_dgrad(dy, w, (H, W), stride=stride, pad=pad, accumulate_into=d1.clone(), split_k=True)
+    assert (d3 - 2 * d1).abs().max().item() < 4e-6 * d1.abs().max().item()
+
+
 @pytest.mark.parametrize('case', CONV_CASES)
 def test_conv_forward(case):
     from object_detection_torch2_amd import ops
