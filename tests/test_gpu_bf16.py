@@ -143,3 +143,28 @@ def test_model_bf16_forward_and_training_close_to_fp32(golden):
     net.load_state_dict(O.init_state(seed=1))
     with torch.no_grad():
         assert torch.equal(net(x), y32)
+
+
+def test_model_bf16_eval_mode_and_graph_replay():
+    """bf16 backbone with running statistics (net.eval(): the apply pass takes the folded scale / shift) stays within bf16 noise of
+    the fp32 eval forward; the forward captured in a HIP graph (haloed buffers allocated before the capture) replays to the same bits."""
+    from oracle import ssd_oracle as O
+    from object_detection_torch2_amd import synth
+    from object_detection_torch2_amd.model import SSD
+    net = SSD(num_classes=21)
+    net.load_state_dict(O.init_state(seed=1))
+    net.to(DEV).eval()
+    x = torch.from_numpy(synth.images(33, 2)).to(DEV)
+    with torch.no_grad():
+        y32 = net(x).clone()
+        net.set_compute_dtype('bf16')
+        y16 = net(x).clone()
+        run = net.graphed_forward(x)
+        y16g = run(x).clone()
+        y16g2 = run(x).clone()
+    rel = ((y16 - y32).norm() / y32.norm()).item()
+    assert rel < 0.1, rel                                   # eval-mode BN of a random-init net amplifies more than train-mode BN
+    assert torch.equal(y16g, y16) and torch.equal(y16g2, y16)
+    net.set_compute_dtype('fp32')
+    with torch.no_grad():
+        assert torch.equal(net(x), y32)
