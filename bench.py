@@ -344,6 +344,12 @@ def main():
                 roof.update(achieved=round(ach_x, 2), frac=round(ach_x / peak, 4), avg_launch_ms=round(ex['ms'] / ex['n'], 4), launches=ex['n'],
                             measured='HIP events around the same launches over 3 extra steps (after one unrecorded step) right after the timed region, streams serialised '
                                      '(agrees with the per-dispatch durations rocprofv3 reports for this command)')
+        if a['direct'] > a['flops'] * 1.01:
+            # SURVEY 8(d) counts a layer's work as direct-convolution flops; the same launches priced that way (kept beside the
+            # executed-flop figure above, which is the one to judge the kernel's use of the matrix pipe by)
+            dq = roof['achieved'] * a['direct'] / a['flops']
+            roof['direct_equivalent'] = dict(achieved=round(dq, 2), frac=round(dq / peak, 4),
+                                             algorithmic_flop_per_launch=round(a['direct'] / a['n']))
         roof['note'] = '; '.join(notes) if notes else None
     eng.prof = None
 
