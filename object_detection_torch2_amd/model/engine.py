@@ -229,10 +229,14 @@ class Engine:
         """bf16 mode (BASELINE configs[3] / [4]): frozen 3x3/s1/p1 backbone layers run on the bf16 patch convolution (conv_bf16.hip),
         reading an ACTIVATED bf16 tensor with a zero halo that the producer's apply pass wrote -- the activations of the backbone are
         bf16 in HBM.  The trainable tail keeps the implicit-GEMM bf16 template (fp32 tensors, operands rounded at staging)."""
-        if not self.bf16 or i <= 0 or i >= min(self.tail_start, len(self.stages)) or os.environ.get('SSD_NO_BF16_PATCH') == '1':
+        if not self.bf16 or i <= 0 or i >= len(self.stages) or i > self.tail_start or os.environ.get('SSD_NO_BF16_PATCH') == '1':
             return False
         c, g = self.stages[i].conv, geo[i]
-        return (c.frozen and not c.is_head and c.k == 3 and c.stride == 1 and c.pad == 1 and c.cin % 32 == 0 and c.cin >= 32
+        if i == self.tail_start and (self.stages[i - 1].pool_pad is not None or self.stages[i - 1].conv.is_head):
+            return False               # its weight gradient reads the fp32 (z, scale, shift) of the stage below: no pool in between
+        # i == tail_start: the first trainable layer (conv_6_1) reads the backbone's last activation; its forward fits the same kernel
+        # (weights repacked when they change), its backward keeps reading the fp32 z + scale / shift of that activation
+        return ((c.frozen or i == self.tail_start) and not c.is_head and c.k == 3 and c.stride == 1 and c.pad == 1 and c.cin % 32 == 0 and c.cin >= 32
                 and c.cout % 64 == 0 and g['wi'] >= 14 and self.lib.ssdhip_conv_bf16_act_bytes(N, g['hi'], g['wi'], c.cin) < (1 << 31)
                 and N * g['hi'] * g['wi'] * c.cout < (1 << 31))
 
@@ -491,10 +495,11 @@ class Engine:
                 patch = self._patch_ok(i, N, geo)
                 nxt_patch = self._patch_ok(i + 1, N, geo)
                 # z of a patch layer is bf16 when only the next layer's apply pass reads it (no head, no fp32 consumer)
-                z_bf16 = patch and nxt_patch and s.head is None and os.environ.get('SSD_BF16_Z', 'bf16') == 'bf16'
+                z_bf16 = (patch and nxt_patch and s.head is None and i + 1 < self.tail_start
+                          and os.environ.get('SSD_BF16_Z', 'bf16') == 'bf16')
                 if patch:
                     w1, b1 = self._weight(c)
-                    key = (w1.data_ptr(), w1._version, 0)
+                    key = (w1.data_ptr(), w1._version, self.m._hip_epoch if not c.frozen else 0)
                     if getattr(c, 'cb_img', None) is None or c.cb_img.device != w1.device:
                         c.cb_img = torch.empty(self.lib.ssdhip_conv_bf16_weight_bytes(c.cout, c.cin), device=w1.device, dtype=torch.uint8)
                         c.cb_key = None
@@ -610,7 +615,10 @@ class Engine:
                     cur, cur_xs = pooled, None
                 else:
                     cur, cur_xs = z, act_xs
-                acts.append((z, act_xs, cur, cur_xs))
+                # what the backward reads as the next stage's input is always an fp32 tensor (+ scale / shift): where the next stage's
+                # FORWARD took the haloed bf16 copy and is trainable (conv_6_1), its weight gradient still reads z and this BN state
+                # (_patch_ok admits that case only without a pool in between)
+                acts.append((z, act_xs, cur, cur_xs) if cur_xs is not None or cur.dtype == torch.float32 else (z, act_xs, z, act_xs))
                 if s.head is not None:
                     off = b['head_off'][s.head_index]
                     with fork.side(after=bb if on_bb else None):   # needs z and this stage's BN scale/shift only; writes its own rows of `out`
