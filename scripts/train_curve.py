@@ -1,4 +1,4 @@
-"""300 train steps (batch 32, fp32, all streams on, no host sync inside the loop) cycling over 8 fixed synthetic batches: the loss
+"""300 train steps (batch 32, fp32 or DTYPE=bf16, all streams on, no host sync inside the loop) cycling over 8 fixed synthetic batches: the loss
 curve and a finite-state check -- evidence that the whole step (mining, backward, Adam, pipelining) trains."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,6 +9,8 @@ from object_detection_torch2_amd.optim import FusedAdam
 dev = 'cuda:0'
 torch.manual_seed(1)
 net = SSD(21).to(dev); df = net.default_bboxes.to(dev)
+if os.environ.get('DTYPE') == 'bf16':          # BASELINE configs[3] form: bf16 forward / backward, fp32 master weights
+    net.set_compute_dtype('bf16')
 opt = FusedAdam(net.train_params(), lr=1e-3, weight_decay=5e-4, on_step=net.hip_weights_changed)
 data = [(torch.from_numpy(synth.images(900 + k, 32)).to(dev), torch.from_numpy(synth.targets(950 + k, 32, g_max=8)).to(dev)) for k in range(8)]
 torch.cuda.synchronize(); ev = torch.cuda.current_stream().record_event()
