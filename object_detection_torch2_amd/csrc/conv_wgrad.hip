@@ -503,7 +503,7 @@ int64_t ssdhip_conv2d_wgrad_ws_bytes(const ssdhip_wgrad_params* p) {
     WgradArgs a;
     plan(p, a);
     int64_t slabs = (int64_t)a.splitK * a.CoutT * a.taps * a.CinT * 4;
-    int64_t bias = (int64_t)64 * a.Cout * 2 * 4;
+    int64_t bias = (int64_t)256 * a.Cout * 2 * 4;
     return slabs + bias;
 }
 
@@ -535,7 +535,7 @@ int ssdhip_conv2d_wgrad(const ssdhip_wgrad_params* p, void* stream) {
     if (p->dbias) {
         float* partial = a.ws + (size_t)a.splitK * a.CoutT * a.taps * a.CinT;
         int MB = cdiv(a.M, 64);
-        if (MB > 64) MB = 64;
+        if (MB > 256) MB = 256;
         const int rows_per_block = cdiv(a.M, MB);
         MB = cdiv(a.M, rows_per_block);
         hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(p->Cout, 64), MB), dim3(256), 0, st, p->dy, (long long)p->dy_batch_stride,
@@ -558,7 +558,7 @@ int64_t ssdhip_conv2d_wgrad_winograd_ws_bytes(const ssdhip_wgrad_params* p) {
     WgradArgs a;
     plan_winograd(p, a, T, Tp, nullptr, nullptr, nullptr);
     int64_t v = (int64_t)16 * Tp * p->Cin * 4, dm = (int64_t)16 * Tp * p->dy_row * 4;
-    int64_t slabs = (int64_t)a.splitK * a.CoutT * 16 * a.CinT * 4, bias = (int64_t)64 * p->Cout * 2 * 4;
+    int64_t slabs = (int64_t)a.splitK * a.CoutT * 16 * a.CinT * 4, bias = (int64_t)256 * p->Cout * 2 * 4;
     return v + dm + slabs + bias;
 }
 
@@ -599,7 +599,7 @@ int ssdhip_conv2d_wgrad_winograd(const ssdhip_wgrad_params* p, void* stream) {
         float* partial = slabs + (size_t)a.splitK * a.CoutT * 16 * a.CinT;
         const int M = p->N * p->Ho * p->Wo;
         int MB = cdiv(M, 64);
-        if (MB > 64) MB = 64;
+        if (MB > 256) MB = 256;
         const int rows_per_block = cdiv(M, MB);
         MB = cdiv(M, rows_per_block);
         hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(p->Cout, 64), MB), dim3(256), 0, st, p->dy, (long long)p->dy_batch_stride,

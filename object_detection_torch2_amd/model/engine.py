@@ -492,8 +492,11 @@ class Engine:
                     for ev in self._readers.pop(i, ()):      # last step's readers of this stage's output / BN state
                         bb.wait_event(ev)
                 st = _lib.stream()
-                patch = self._patch_ok(i, N, geo)
-                nxt_patch = self._patch_ok(i + 1, N, geo)
+                pk = b.setdefault('patch', {})               # per buffer set: (stage, mode switches) -> runs on the bf16 patch kernel
+                for j in (i, i + 1):
+                    if (j, self.bf16) not in pk:
+                        pk[(j, self.bf16)] = self._patch_ok(j, N, geo)
+                patch, nxt_patch = pk[(i, self.bf16)], pk[(i + 1, self.bf16)]
                 # z of a patch layer is bf16 when only the next layer's apply pass reads it (no head, no fp32 consumer)
                 z_bf16 = (patch and nxt_patch and s.head is None and i + 1 < self.tail_start
                           and os.environ.get('SSD_BF16_Z', 'bf16') == 'bf16')
