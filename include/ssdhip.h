@@ -252,8 +252,8 @@ int ssdhip_wino_fused_conv(const float* x, const float* upk, const float* bias, 
  * model/vgg16.py:33 on bf16 activations kept in HBM, v_mfma_f32_32x32x16_bf16 with fp32 accumulation, fed by LDS-DMA from an image
  * patch that serves all 9 taps.  Opt-in (SSD.set_compute_dtype('bf16')); never the fp32 headline path.
  * a = ACTIVATED input (BatchNorm + ReLU applied), bf16, NHWC with a one-pixel zero halo: (N, H+2, W+2, Cin) inside a zero-initialised
- * allocation of ssdhip_conv_bf16_act_bytes(N,H,W,Cin) bytes (the slack behind the tensor is read, never written); Cin % 32 == 0,
- * W >= 14.  wpk = ssdhip_conv_bf16_pack(w OIHW (Cout,Cin,3,3) fp32), ssdhip_conv_bf16_weight_bytes(Cout,Cin) bytes, Cout % 64 == 0.
+ * allocation of ssdhip_conv_bf16_act_bytes(N,H,W,Cin) bytes (< 4 GiB; the slack behind the tensor is read, never written);
+ * Cin % 32 == 0, W >= 14.  wpk = ssdhip_conv_bf16_pack(w OIHW (Cout,Cin,3,3) fp32), ssdhip_conv_bf16_weight_bytes(Cout,Cin) bytes, Cout % 64 == 0.
  * z (N,H,W,Cout) = conv + bias, fp32 (z_bf16 = 0) or bf16 (1); stats NULL or (ssdhip_conv_bf16_stat_rows(N,H,W), Cout, 2) fp32
  * partial sum / sum of squares of the fp32 values.  max_blocks as in ssdhip_wino_fused_conv.  Returns the stats rows or < 0.   */
 int64_t ssdhip_conv_bf16_weight_bytes(int Cout, int Cin);

@@ -173,16 +173,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int q = (wave * CB_PPW + k) * 64 + lane, p = q >> 2;
         const int lc = (q & 3) ^ ((p >> 2) & 3);
         const int rel = a.mode ? p : (p / CB_TILE_PITCH) * a.Wp + p % CB_TILE_PITCH;
-        dof[k] = p < a.npix ? (unsigned)(rel * a.C * 2 + lc * 16) : 0x80000000u;       // beyond num_records: lands as zeros
+        dof[k] = p < a.npix ? (unsigned)rel * (unsigned)(a.C * 2) + (unsigned)(lc * 16) : 0u;     // slots behind the patch are never read: any valid source
     }
     const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.a), 0, a.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wpk), 0, a.w_bytes, 0x00020000);
     auto dma_a = [&](int k, int stage, unsigned soff) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ar, (lptr_t)(lds + CB_A_OFF + stage * CB_STAGE + (wave * CB_PPW + k) * 1024), 16, dof[k], soff, 0, 0);
     };
-    // weight image of step sidx (of this block's channel tile) -> buffer buf: one piece per wave (64-channel tiles: waves 4-7
-    // move nothing; their piece reads beyond num_records and lands as zeros in the unused half of the buffer)
-    const unsigned b_vo = wave * 1024 < IMG ? (unsigned)(wave * 1024 + lane * 16) : 0x80000000u;
+    // weight image of step sidx (of this block's channel tile) -> buffer buf: one piece per wave (64-channel tiles: the pieces of
+    // waves 4-7 re-read the image's first KiB into the unused half of the buffer)
+    const unsigned b_vo = wave * 1024 < IMG ? (unsigned)(wave * 1024 + lane * 16) : (unsigned)(lane * 16);
     auto dma_b = [&](int buf, int sidx) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lptr_t)(lds + CB_B_OFF + buf * CB_BBUF + wave * 1024), 16, b_vo, (nb * steps + sidx) * IMG, 0, 0);
     };
@@ -409,7 +409,7 @@ int ssdhip_conv_bf16(const void* a, const void* wpk, const float* bias, void* z,
     SSDHIP_REQUIRE(a && wpk && z && N > 0 && H > 0 && W > 0 && max_blocks >= 0, "conv_bf16: bad arguments");
     SSDHIP_REQUIRE(Cin >= 32 && Cin % 32 == 0 && Cout > 0 && Cout % 64 == 0, "conv_bf16: Cin must be a multiple of 32 and Cout of 64");
     const int64_t abytes = ssdhip_conv_bf16_act_bytes(N, H, W, Cin);
-    SSDHIP_REQUIRE(abytes > 0 && abytes < (1ll << 31) && (int64_t)N * H * W * Cout < (1ll << 31), "conv_bf16: tensors must stay below 2 GiB (32-bit offsets)");
+    SSDHIP_REQUIRE(abytes > 0 && abytes < (1ll << 32) && (int64_t)N * H * W * Cout < (1ll << 31), "conv_bf16: the haloed input must stay below 4 GiB (32-bit byte offsets) and the output below 2^31 elements");
     SSDHIP_REQUIRE(W >= 14, "conv_bf16: map too narrow (W >= 14)");
     static DeviceOnce attr;
     if (const int dev = attr.pending(); dev != DeviceOnce::kDone) {

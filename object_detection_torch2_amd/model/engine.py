@@ -237,7 +237,7 @@ class Engine:
         # i == tail_start: the first trainable layer (conv_6_1) reads the backbone's last activation; its forward fits the same kernel
         # (weights repacked when they change), its backward keeps reading the fp32 z + scale / shift of that activation
         return ((c.frozen or i == self.tail_start) and not c.is_head and c.k == 3 and c.stride == 1 and c.pad == 1 and c.cin % 32 == 0 and c.cin >= 32
-                and c.cout % 64 == 0 and g['wi'] >= 14 and self.lib.ssdhip_conv_bf16_act_bytes(N, g['hi'], g['wi'], c.cin) < (1 << 31)
+                and c.cout % 64 == 0 and g['wi'] >= 14 and self.lib.ssdhip_conv_bf16_act_bytes(N, g['hi'], g['wi'], c.cin) < (1 << 32)
                 and N * g['hi'] * g['wi'] * c.cout < (1 << 31))
 
     @staticmethod
