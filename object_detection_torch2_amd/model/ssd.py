@@ -260,9 +260,10 @@ class SSD(nn.Module):
         return self
 
     def set_compute_dtype(self, dtype: str):
-        """'fp32' (default; exact-fp32 MFMA, Winograd for the deep 3x3 layers) or 'bf16' (BASELINE configs[3]: conv forward and
-        data gradients on the bf16 MFMA with fp32 accumulation, operands rounded while staged; parameters, activations,
-        BN statistics, weight gradients, loss and Adam stay fp32 = the "fp32 master" side)."""
+        """'fp32' (default; exact-fp32 MFMA, Winograd for the deep 3x3 layers) or 'bf16' (BASELINE configs[3] / [4]: the frozen
+        backbone keeps bf16 activations in HBM and runs on the bf16 patch convolution; the trainable tail's forward convolutions,
+        data and weight gradients round their operands to bf16 while staging; every product accumulates in fp32; parameters,
+        gradients, BN statistics, loss and Adam stay fp32 = the "fp32 master" side)."""
         if dtype not in ('fp32', 'bf16'):
             raise ValueError(f"compute dtype must be 'fp32' or 'bf16', got {dtype!r}")
         self.compute_dtype = dtype

@@ -12,6 +12,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 25
 def run(single, sync_each, overlap=False):
     net = SSD(21); net.load_state_dict(O.init_state(1)); net.to(DEV)
+    net.set_compute_dtype(os.environ.get('DTYPE', 'fp32'))
     net._engine().single_stream = single
     opt = FusedAdam(net.train_params(), lr=1e-3, weight_decay=5e-4, on_step=net.hip_weights_changed)
     df = net.default_bboxes.to(DEV)

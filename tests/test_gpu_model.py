@@ -303,15 +303,18 @@ def test_training_reduces_the_loss_on_a_fixed_batch(env):
     assert not bad, bad
 
 
-def test_stream_pipelining_is_bit_identical_to_single_stream(env):
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_stream_pipelining_is_bit_identical_to_single_stream(env, dtype):
     """Backbone stream / side stream / main stream (engine.py) only reorder independent launches: four train steps on changing
-    batches give bit-identical losses, parameters and running statistics with and without them."""
+    batches give bit-identical losses, parameters and running statistics with and without them -- also in bf16 mode, whose backbone
+    hands the tail a haloed bf16 copy of its last activation besides the fp32 one."""
     from object_detection_torch2_amd.optim import FusedAdam
     synth = env['synth']
     batches = [(torch.from_numpy(synth.images(300 + k, 4)).to(DEV), torch.from_numpy(synth.targets(310 + k, 4, g_max=8)).to(DEV)) for k in range(4)]
     results = []
     for single, overlap in ((True, False), (False, False), (False, True)):
         net = make_net(env)
+        net.set_compute_dtype(dtype)
         net._engine().single_stream = single
         torch.cuda.synchronize()
         ready = torch.cuda.current_stream().record_event() if overlap else None
