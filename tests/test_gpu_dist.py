@@ -30,18 +30,20 @@ def test_two_rank_pipelined_steps_match_serialised_streams():
     assert r.stdout.count('pipelined == serialised: True; ranks identical: True') == 2
 
 
-def test_bench_self_launch_two_ranks_on_one_gpu():
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_bench_self_launch_two_ranks_on_one_gpu(dtype):
     """The driver's command line for N > 1 (`python bench.py --gpus N ...`, no launcher): the parent starts the ranks; here 2 ranks share
-    the box's one GPU over gloo.  One JSON line, world size 2 seen by the all-reduce, communication fields present."""
+    the box's one GPU over gloo.  One JSON line, world size 2 seen by the all-reduce, communication fields present.  bf16 = the
+    data-parallel form of BASELINE configs[3] (fp32 gradients in the all-reduce, fp32 master weights)."""
     import json
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
     env.update(SSD_DIST_BACKEND='gloo', SSD_FORCE_DEVICE='0')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2', '--batch', '4',
-                        '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900)
+                        '--no-cpu-baseline', '--dtype', dtype], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1
     line = lines[0]
     assert line['n_gpus'] == 2 and line['ranks'] == 2 and line['config']['global_batch'] == 8 and line['scaling'] == 'weak'
     assert line['value'] > 0 and line['comm_ms_per_step'] > 0 and 'comm_exposed_ms_per_step' in line
-    assert line['roofline']['bound'] == 'mfma'
+    assert line['roofline']['bound'] == 'mfma' and line['dtype'] == ('bf16' if dtype == 'bf16' else 'f32')
