@@ -17,6 +17,7 @@ out_o = O.forward(sd, torch.from_numpy(ims), training=True); o = out_o.detach().
 lref = float(O.loss(o, tg, df)); out_o.backward(torch.from_numpy(O.loss_grad(o, tg, df)))
 print(f'oracle forward + backward on the host: {time.time() - t0:.1f} s', flush=True)
 net = SSD(21); net.load_state_dict(O.init_state(1)); net.to(DEV)
+net.set_compute_dtype(os.environ.get('DTYPE', 'fp32'))          # DTYPE=bf16: the same comparison for BASELINE configs[3]'s form (fp32 oracle)
 out = net(torch.from_numpy(ims).to(DEV)); loss = net.loss(out, torch.from_numpy(tg).to(DEV), torch.from_numpy(df).to(DEV)); loss.backward()
 err = np.abs(out.detach().cpu().numpy() - o)
 print(f'N = {N}: max |out - oracle| = {err.max():.3e} (mean {err.mean():.2e}, |out| max {np.abs(o).max():.2f}); loss {loss.item():.6f} vs oracle {lref:.6f} (diff {abs(loss.item() - lref):.2e})')
