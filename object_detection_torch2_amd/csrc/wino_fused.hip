@@ -454,6 +454,310 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef WF_TIE_TILE
 }
 
+
+// ---- 8-wave form of the same kernel (the one the library launches): two waves per SIMD, so that one wave's DMA issue slots, waits and barriers run
+// under the other wave's MFMAs.  A wave may then hold 128 accumulators: 16 tiles x 32 output channels x 16 planes on
+// v_mfma_f32_16x16x4_f32 (C/D: column = lane & 15, row = 4 (lane >> 4) + register -- still the output channel on the lane and the
+// tile on the register index, so the output transform stays register-local).  Same item, same LDS plan, same operand images, same
+// packed weights and geometry records as wino_fused_kernel; what changes is who does what:
+//   MFMA    wave (wm = wave >> 1, wn = wave & 1): tiles 16 wm .., channels 32 wn ..; per plane one ds_read_b64 of A (lane (i, kq) takes
+//           channels 2 kq, 2 kq + 1 of tile row i = the k of its two MFMAs) and two of B, four MFMAs
+//   stage   thread (tile = lane, hh = wave & 1, q = (wave >> 1) & 1, half = wave >> 2): half a patch x 2 channels (8-B LDS accesses)
+//   DMA     weight image: 4 pieces per wave; raw tile: waves 0-3 three pieces, waves 4-7 two; record: waves 0-3
+template <bool XFORM>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_fused8_kernel(WfArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)lds;
+    const int G = gridDim.x;
+    int nb, mb0, mbstep = G / a.NB, mb_end = a.MB;
+    if (G % (8 * a.NB) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, L = (a.MB + 7) >> 3;
+        nb = slot % a.NB;
+        mbstep = (G >> 3) / a.NB;
+        mb0 = xcd * L + slot / a.NB;
+        mb_end = min(a.MB, (xcd + 1) * L);
+    } else {
+        nb = blockIdx.x % a.NB;
+        mb0 = blockIdx.x / a.NB;
+    }
+    if (mb0 >= mb_end) return;
+    const int cnt = (mb_end - mb0 + mbstep - 1) / mbstep;
+    const int n0 = nb * WF_COUT;
+    const int KT = a.KT;
+
+    if (XFORM) {
+        float* ss = reinterpret_cast<float*>(lds + WF_SS_OFF);
+        for (int c = tid; c < a.C; c += 512) { ss[c] = a.scale[c]; ss[WF_MAXC + c] = a.shift[c]; }
+    }
+
+    // staging role
+    const int hh = wave & 1, q = (wave >> 1) & 1, half = wave >> 2;
+    // raw-tile DMA pieces of this wave: piece ids P = 0 .. 19 (quad P / 10, 64 slots P % 10)
+    const int np = wave < 4 ? 3 : 2, p_first = wave < 4 ? 3 * wave : 12 + 2 * (wave - 4);
+    unsigned dof[3], pb[3];
+    float hi[3][4];
+    int recN[3];
+    i32x4 tileN;
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(a.geo), 0, (unsigned)a.MB * WF_REC_BYTES, 0x00020000);
+    const unsigned rec_vo = (unsigned)(wave * 1024 + lane * 16);
+    auto dma_rec = [&](int j, int slot) {
+        if (rec_vo < (unsigned)WF_REC_BYTES)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (lptr_t)(lds + WF_REC_OFF + (slot & 1) * WF_REC_BYTES + wave * 1024), 16, rec_vo,
+                                                     (mb0 + j * mbstep) * WF_REC_BYTES, 0, 0);
+    };
+    auto read_slots = [&](int j) {
+        const unsigned rb = lds0 + (unsigned)(WF_REC_OFF + (j & 1) * WF_REC_BYTES);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int P = p_first + (k < np ? k : 0);
+            asm volatile("ds_read_b32 %0, %1" : "=v"(recN[k]) : "v"(rb + (unsigned)((64 * (P % 10) + lane) * 4)));
+        }
+    };
+    auto read_tile = [&](int j) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(tileN) : "v"(lds0 + (unsigned)(WF_REC_OFF + (j & 1) * WF_REC_BYTES + WF_SLOTS * 4 + lane * 16)));
+    };
+#define WF8_TIE_SLOTS() asm volatile("" : "+v"(recN[0]), "+v"(recN[1]), "+v"(recN[2]))
+#define WF8_TIE_TILE() asm volatile("" : "+v"(tileN))
+    auto adopt_dof = [&]() {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dof[k] = recN[k] < 0 ? 0x80000000u : (unsigned)(recN[k] * a.C * 4);
+    };
+    auto adopt_tile = [&]() {
+        const bool tv = (tileN.z >> 8) & 1;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int pr = hh ? 3 - r : r;
+            pb[r] = lds0 + (unsigned)(WF_RAW_OFF + q * WF_QUAD + half * 8 + (tv ? (tileN.x + pr * tileN.y) * 16 : 0));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hi[r][j] = (((tileN.z >> pr) & 1) && ((tileN.z >> (4 + j)) & 1)) ? __builtin_inff() : 0.0f;
+        }
+    };
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+    auto dma_raw = [&](int g) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k < np) {
+                const int P = p_first + k, quad = P / 10;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lptr_t)(lds + WF_RAW_OFF + quad * WF_QUAD + (P % 10) * 1024), 16, dof[k], g * 32 + quad * 16, 0, 0);
+            }
+    };
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.upk), 0, (unsigned)(16u * a.Cout * a.C * 4u), 0x00020000);
+    const unsigned b_vo = (unsigned)(wave * (WF_OPER / 8) + lane * 16);
+    auto dma_b = [&](int g) {
+        const int so = (nb * a.KT + g) * WF_OPER;
+        char* d = lds + WF_B_OFF + (g & 1) * WF_OPER + wave * (WF_OPER / 8);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (lptr_t)(d + k * 1024), 16, b_vo, so + k * 1024, 0, 0);
+    };
+
+    f32x2 P[3][4], sc, sh, rx[4], ry[4];
+    sc = (f32x2){1.f, 1.f}; sh = (f32x2){0.f, 0.f};
+    const unsigned ss_rd = lds0 + (unsigned)(WF_SS_OFF + q * 16 + half * 8);
+    auto read_patch = [&](int g) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(P[r][j]) : "v"(pb[r]), "n"(j * 16));
+        if (XFORM) {
+            asm volatile("ds_read_b64 %0, %1" : "=v"(sc) : "v"(ss_rd + (unsigned)(g * 32)));
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(sh) : "v"(ss_rd + (unsigned)(g * 32)), "n"(WF_MAXC * 4));
+        }
+    };
+#define WF8_TIE_P()                                                                                                                  \
+    asm volatile("" : "+v"(P[0][0]), "+v"(P[0][1]), "+v"(P[0][2]), "+v"(P[0][3]), "+v"(P[1][0]), "+v"(P[1][1]), "+v"(P[1][2]),        \
+                      "+v"(P[1][3]), "+v"(P[2][0]), "+v"(P[2][1]), "+v"(P[2][2]), "+v"(P[2][3]), "+v"(sc), "+v"(sh))
+    auto act = [&](f32x2 f, float h) -> f32x2 {
+        if (XFORM) {
+            f.x = __builtin_amdgcn_fmed3f(__builtin_fmaf(f.x, sc.x, sh.x), 0.f, h);
+            f.y = __builtin_amdgcn_fmed3f(__builtin_fmaf(f.y, sc.y, sh.y), 0.f, h);
+        }
+        return f;
+    };
+    const float ysign = hh ? -1.f : 1.f;
+    const unsigned wr_lane = (unsigned)(lane * 32 + ((q ^ ((lane >> 3) & 1)) * 16) + half * 8);
+    const unsigned x_wr = lds0 + (unsigned)(WF_A_OFF + (hh ? 12 : 0) * WF_PLANE) + wr_lane;
+    const unsigned y_wr = lds0 + (unsigned)(WF_A_OFF + (hh ? 8 : 4) * WF_PLANE) + wr_lane;
+    auto rows_of = [&](int j) {
+        const f32x2 l0 = act(P[0][j], hi[0][j]), l1 = act(P[1][j], hi[1][j]), l2 = act(P[2][j], hi[2][j]);
+        rx[j] = l0 - l2;
+        ry[j].x = __builtin_fmaf(ysign, l2.x, l1.x); ry[j].y = __builtin_fmaf(ysign, l2.y, l1.y);
+    };
+    auto planes_of = [&](int i, unsigned abase) {
+        const f32x2* r = i == 0 ? rx : ry;
+        const unsigned dst = (i == 0 ? x_wr : y_wr) + abase;
+        const f32x2 o0 = r[0] - r[2], o1 = r[1] + r[2], o2 = r[2] - r[1], o3 = r[1] - r[3];
+        asm volatile("ds_write_b64 %0, %1" ::"v"(dst), "v"(o0) : "memory");
+        asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(dst), "v"(o1), "n"(WF_PLANE) : "memory");
+        asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(dst), "v"(o2), "n"(2 * WF_PLANE) : "memory");
+        asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(dst), "v"(o3), "n"(3 * WF_PLANE) : "memory");
+    };
+
+    // ---- prologue
+    dma_rec(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    read_slots(0);
+    read_tile(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    WF8_TIE_SLOTS();
+    WF8_TIE_TILE();
+    adopt_dof();
+    adopt_tile();
+    dma_raw(0);
+    dma_b(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_patch(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    WF8_TIE_P();
+    __builtin_amdgcn_s_barrier();
+    dma_raw(1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rows_of(j);
+    planes_of(0, 0);
+    planes_of(1, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // operand fragments: lane (i = lane & 15, kq = lane >> 4) takes the 8 bytes (channels 2 kq, 2 kq + 1) of row i of the wave's 16
+    // tile rows / of each of its two groups of 16 channel rows; the 16-B halves of a row are swapped where (row >> 3) & 1
+    const int li = lane & 15, kq = lane >> 4;
+    const unsigned f_lo = (unsigned)(li * 32 + ((kq * 8) ^ (((li >> 3) & 1) * 16)));
+    const unsigned a_rd = lds0 + (unsigned)(WF_A_OFF + 16 * wm * 32) + f_lo;
+    const unsigned b_rd = lds0 + (unsigned)(WF_B_OFF + 32 * wn * 32) + f_lo;
+    const int co0 = n0 + 32 * wn + li;
+    const float bv0 = a.bias ? a.bias[co0] : 0.f, bv1 = a.bias ? a.bias[co0 + 16] : 0.f;
+    const int WC = a.W * a.Cout;
+
+#pragma clang loop unroll(disable)
+    for (int j = 0; j < cnt; ++j) {
+        f32x4 acc[16][2];
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[p][c][e] = 0.f;
+#pragma clang loop unroll(disable)
+        for (int g = 0; g < KT; ++g) {
+            const int jn = j + 1 < cnt ? j + 1 : j;
+            const unsigned cur = (unsigned)(g & 1) * WF_OPER, nxt = cur ^ WF_OPER;
+            const unsigned ab = a_rd + cur, bb = b_rd + cur;
+            const int g1 = g + 1 < KT ? g + 1 : 0, g2 = g + 2 < KT ? g + 2 : g + 2 - KT;
+            f32x2 fa[2], fb0[2], fb1[2];
+            asm volatile("ds_read_b64 %0, %1" : "=v"(fa[0]) : "v"(ab));
+            asm volatile("ds_read_b64 %0, %1" : "=v"(fb0[0]) : "v"(bb));
+            asm volatile("ds_read_b64 %0, %1 offset:512" : "=v"(fb1[0]) : "v"(bb));
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const int c = p & 1;
+                if (p < 15) {
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fa[c ^ 1]) : "v"(ab), "n"((p + 1) * WF_PLANE));
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fb0[c ^ 1]) : "v"(bb), "n"((p + 1) * WF_PLANE));
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fb1[c ^ 1]) : "v"(bb), "n"((p + 1) * WF_PLANE + 512));
+                }
+                if (p == 0) {
+                    dma_b(g1);
+                    if (g == 0) dma_rec(jn, j + 1);
+                    read_patch(g1);
+                    if (g == KT - 3) read_slots(j + 1);
+                    if (g == KT - 2) read_tile(j + 1);
+                    // this plane's three fragments were issued first: at most 15 newer reads may stay outstanding (4-bit field)
+                    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(fa[c]), "+v"(fb0[c]), "+v"(fb1[c]) : "n"(15));
+                } else if (p == 1) {
+                    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa[c]), "+v"(fb0[c]), "+v"(fb1[c]));
+                    WF8_TIE_P();
+                    WF8_TIE_SLOTS();
+                    WF8_TIE_TILE();
+                    __builtin_amdgcn_s_barrier();
+                    dma_raw(g2);
+                } else if (p < 15) {
+                    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa[c]), "+v"(fb0[c]), "+v"(fb1[c]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[c]), "+v"(fb0[c]), "+v"(fb1[c]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].x, fb0[c].x, acc[p][0], 0, 0, 0);
+                acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].x, fb1[c].x, acc[p][1], 0, 0, 0);
+                acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].y, fb0[c].y, acc[p][0], 0, 0, 0);
+                acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].y, fb1[c].y, acc[p][1], 0, 0, 0);
+                if (p >= 2 && p < 6) rows_of(p - 2);
+                if (p == 6) planes_of(0, nxt);
+                if (p == 7) planes_of(1, nxt);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (g == KT - 3) adopt_dof();
+            if (g == KT - 2) adopt_tile();
+        }
+
+        // ---- output transform: per (channel group cg, register e): tile = 16 wm + 4 (lane >> 4) + e, channel = co0 + 16 cg
+        const int mb = mb0 + j * mbstep;
+        const char* rec = lds + WF_REC_OFF + (j & 1) * WF_REC_BYTES + WF_SLOTS * 4;
+        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = 16 * wm + 4 * kq + e;
+            const int2 ent = *reinterpret_cast<const int2*>(rec + i * 16 + 8);
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg) {
+                float r[2][4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    r[0][jj] = (acc[jj][cg][e] + acc[4 + jj][cg][e]) + acc[8 + jj][cg][e];
+                    r[1][jj] = (acc[4 + jj][cg][e] - acc[8 + jj][cg][e]) - acc[12 + jj][cg][e];
+                }
+                const float bv = cg ? bv1 : bv0;
+                float* zp = a.z + (size_t)ent.y * a.Cout + co0 + 16 * cg;
+#pragma unroll
+                for (int aa = 0; aa < 2; ++aa) {
+                    const float y0 = ((r[aa][0] + r[aa][1]) + r[aa][2]) + bv;
+                    const float y1 = ((r[aa][1] - r[aa][2]) - r[aa][3]) + bv;
+                    const bool rowok = ((ent.x >> 8) & 1) && (aa == 0 || ((ent.x >> 9) & 1));
+                    if (rowok) {
+                        zp[aa * WC] = y0;
+                        s1[cg] += y0; s2[cg] += y0 * y0;
+                        if ((ent.x >> 10) & 1) {
+                            zp[aa * WC + a.Cout] = y1;
+                            s1[cg] += y1; s2[cg] += y1 * y1;
+                        }
+                    }
+                }
+            }
+        }
+        if (a.stats != nullptr) {
+            // the weight image of the last K-step (buffer (KT - 1) & 1 = 1: KT is even) is free until the next step's DMA
+            float* red = reinterpret_cast<float*>(lds + WF_B_OFF + WF_OPER);
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg) {
+                s1[cg] += __shfl_xor(s1[cg], 16, 64); s1[cg] += __shfl_xor(s1[cg], 32, 64);
+                s2[cg] += __shfl_xor(s2[cg], 16, 64); s2[cg] += __shfl_xor(s2[cg], 32, 64);
+                if (lane < 16) {
+                    red[(wm * 64 + 32 * wn + 16 * cg + lane) * 2] = s1[cg];
+                    red[(wm * 64 + 32 * wn + 16 * cg + lane) * 2 + 1] = s2[cg];
+                }
+            }
+            __syncthreads();
+            if (tid < 64) {
+                float* o = a.stats + ((size_t)mb * a.Cout + n0 + tid) * 2;
+                o[0] = (red[tid * 2] + red[(64 + tid) * 2]) + (red[(128 + tid) * 2] + red[(192 + tid) * 2]);
+                o[1] = (red[tid * 2 + 1] + red[(64 + tid) * 2 + 1]) + (red[(128 + tid) * 2 + 1] + red[(192 + tid) * 2 + 1]);
+            }
+        }
+        __syncthreads();
+    }
+#undef WF8_TIE_P
+#undef WF8_TIE_SLOTS
+#undef WF8_TIE_TILE
+}
+
 }  // namespace
 
 extern "C" {
@@ -552,7 +856,20 @@ int ssdhip_wino_fused_conv(const float* x, const float* upk, const float* bias, 
 #undef WF_ABL_CASE
 #endif
     (void)abl;
-    if (in_scale) hipLaunchKernelGGL(wino_fused_kernel<true>, grid, block, WF_LDS, st, a);
+    int eight = 1;         // the 8-wave form: 6-15 % faster on every layer (scripts/wf_bench.py with SSDHIP_WF8=0 / 1, profiles/r02_t_*)
+#ifdef SSDHIP_PROBES
+    if (const char* e = getenv("SSDHIP_WF8")) eight = atoi(e);
+#endif
+    if (eight) {
+        static DeviceOnce once8;
+        if (const int d = once8.pending(); d != DeviceOnce::kDone) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS);
+            once8.mark(d);
+        }
+        if (in_scale) hipLaunchKernelGGL(wino_fused8_kernel<true>, grid, dim3(512), WF_LDS, st, a);
+        else hipLaunchKernelGGL(wino_fused8_kernel<false>, grid, dim3(512), WF_LDS, st, a);
+    } else if (in_scale) hipLaunchKernelGGL(wino_fused_kernel<true>, grid, block, WF_LDS, st, a);
     else hipLaunchKernelGGL(wino_fused_kernel<false>, grid, block, WF_LDS, st, a);
     SSDHIP_CHECK_LAUNCH();
     return a.MB;      // rows of the BatchNorm partial table
