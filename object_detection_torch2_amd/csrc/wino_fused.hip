@@ -9,6 +9,11 @@
 // arithmetic, no shuffle, no LDS.  16 planes x 16 registers = 256 accumulators = the AGPR half of the 512-register file at one
 // wave per SIMD.
 //
+// Two forms of the kernel share everything described below except the wave layout: the library launches the 8-WAVE form
+// (wino_fused8_kernel: two waves per SIMD, wave = 16 tiles x 32 channels x 16 planes on v_mfma_f32_16x16x4_f32, 128 accumulators;
+// one wave's DMA issue slots, waits and barriers run under its partner's MFMAs: 6-15 % faster on every layer); the 4-wave form the
+// text below was written for (one wave per SIMD, 32 x 32 x 16 planes on v_mfma_f32_32x32x2_f32) is kept in probe builds.
+//
 // What bounds it (measured, scripts/wf_bench.py + scripts/wf_pmc.sh): the fp32 MFMA runs at the fp32 VECTOR rate and shares
 // the SIMD's fp32 lanes with the VALU, so the input transform is not free beside it -- every VALU instruction of the loop costs
 // the matrix pipe 2-3 cycles, and the clock drops from 2.40 to 2.14 GHz when the VALU works beside the MFMAs.  Hence the
@@ -154,6 +159,8 @@ __global__ __launch_bounds__(256) void wino_fused_geo_kernel(int* __restrict__ g
     }
 }
 
+#ifdef SSDHIP_PROBES
+// The 4-wave form (one wave per SIMD, 256 accumulators per wave on v_mfma_f32_32x32x2_f32): kept in probe builds for A/B runs.
 // ABL (probe builds only, wrong results by design): bit 0 = no raw-tile DMA in the K loop, bit 1 = no weight DMA in the K loop,
 // bit 2 = no activation / input transform in the K loop, bit 3 = no output stores, bit 4 = one K-step per item
 template <bool XFORM, int ABL = 0>
@@ -454,6 +461,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef WF_TIE_TILE
 }
 
+
+#endif  // SSDHIP_PROBES
 
 // ---- 8-wave form of the same kernel (the one the library launches): two waves per SIMD, so that one wave's DMA issue slots, waits and barriers run
 // under the other wave's MFMAs.  A wave may then hold 128 accumulators: 16 tiles x 32 output channels x 16 planes on
@@ -818,8 +827,13 @@ int ssdhip_wino_fused_conv(const float* x, const float* upk, const float* bias, 
 #endif
     static DeviceOnce attr;
     if (const int dev = attr.pending(); dev != DeviceOnce::kDone) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) != hipSuccess) {
+        bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) == hipSuccess &&
+                  hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) == hipSuccess;
+#ifdef SSDHIP_PROBES
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) == hipSuccess &&
+             hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) == hipSuccess;
+#endif
+        if (!ok) {
             ssdhip_set_error("wino_fused_conv: cannot enable 160 KiB dynamic LDS");
             return SSDHIP_ELAUNCH;
         }
@@ -856,21 +870,19 @@ int ssdhip_wino_fused_conv(const float* x, const float* upk, const float* bias, 
 #undef WF_ABL_CASE
 #endif
     (void)abl;
-    int eight = 1;         // the 8-wave form: 6-15 % faster on every layer (scripts/wf_bench.py with SSDHIP_WF8=0 / 1, profiles/r02_t_*)
+    (void)block;
+    // The library launches the 8-wave form (6-15 % faster on every layer: scripts/wf_bench.py with SSDHIP_WF8=0 / 1,
+    // profiles/r02_t_*); the 4-wave form it grew out of and its timing-only ablations exist in probe builds only.
 #ifdef SSDHIP_PROBES
-    if (const char* e = getenv("SSDHIP_WF8")) eight = atoi(e);
+    if (const char* e = getenv("SSDHIP_WF8"); e && atoi(e) == 0) {
+        if (in_scale) hipLaunchKernelGGL(wino_fused_kernel<true>, grid, block, WF_LDS, st, a);
+        else hipLaunchKernelGGL(wino_fused_kernel<false>, grid, block, WF_LDS, st, a);
+        SSDHIP_CHECK_LAUNCH();
+        return a.MB;
+    }
 #endif
-    if (eight) {
-        static DeviceOnce once8;
-        if (const int d = once8.pending(); d != DeviceOnce::kDone) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS);
-            once8.mark(d);
-        }
-        if (in_scale) hipLaunchKernelGGL(wino_fused8_kernel<true>, grid, dim3(512), WF_LDS, st, a);
-        else hipLaunchKernelGGL(wino_fused8_kernel<false>, grid, dim3(512), WF_LDS, st, a);
-    } else if (in_scale) hipLaunchKernelGGL(wino_fused_kernel<true>, grid, block, WF_LDS, st, a);
-    else hipLaunchKernelGGL(wino_fused_kernel<false>, grid, block, WF_LDS, st, a);
+    if (in_scale) hipLaunchKernelGGL(wino_fused8_kernel<true>, grid, dim3(512), WF_LDS, st, a);
+    else hipLaunchKernelGGL(wino_fused8_kernel<false>, grid, dim3(512), WF_LDS, st, a);
     SSDHIP_CHECK_LAUNCH();
     return a.MB;      // rows of the BatchNorm partial table
 }

@@ -12,12 +12,12 @@ import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob('$OUT/sq/*/*_counter_collection.csv'):
     for r in csv.DictReader(open(f)):
-        if 'wino_fused_kernel' in r['Kernel_Name'] or 'gemm_planes' in r['Kernel_Name']:
+        if "wino_fused" in r["Kernel_Name"] or "gemm_planes" in r["Kernel_Name"]:
             agg[r['Kernel_Name'].split('(')[0][-60:]][r['Counter_Name']].append(float(r['Counter_Value']))
 dur = collections.defaultdict(list)
 for f in glob.glob('$OUT/trace/*/*_kernel_trace.csv'):
     for r in csv.DictReader(open(f)):
-        if 'wino_fused_kernel' in r['Kernel_Name'] or 'gemm_planes' in r['Kernel_Name']:
+        if "wino_fused" in r["Kernel_Name"] or "gemm_planes" in r["Kernel_Name"]:
             dur[r['Kernel_Name'].split('(')[0][-60:]].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 for k, cs in sorted(agg.items()):
     m = {c: sum(v) / len(v) for c, v in cs.items()}
