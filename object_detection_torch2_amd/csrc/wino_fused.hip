@@ -115,7 +115,7 @@ __global__ void wino_fused_pack_kernel(const float* __restrict__ w, float* __res
 // Geometry of tile block mb = its 64 consecutive tiles t0 .. t0 + 63 (row-major over (n, th, tw)): segment 0 is the rest of tile
 // row R0 from column tw0 (len0 tiles), segments 1.. are whole tile rows, the last one possibly cut short.  Segment k owns the
 // pixel strip rows 2 th - 1 .. 2 th + 2, columns 2 tws - 1 .. 2 (tws + len) of its image: 4 x (2 len + 2) raw-tile slots.
-// Record: slot -> pixel index (n H + h) W + w or -1 (outside the image / unused); tile -> {slot of patch position (0, 0), slots per
+// Record: raw-tile position (even slots, then odd slots) -> pixel index (n H + h) W + w or -1 (outside the image / unused); tile -> {slot of patch position (0, 0), slots per
 // patch row, masks (bits 0-3 patch rows inside the image, 4-7 patch columns, 8 tile exists, 9 / 10 second output row / column
 // exists), output pixel index (n H + 2 th) W + 2 tw}.  One block per tile block; depends on (N, H, W) only.
 __global__ __launch_bounds__(256) void wino_fused_geo_kernel(int* __restrict__ geo, int H, int W, int TH, int TW, int T, int RT) {
@@ -127,7 +127,10 @@ __global__ __launch_bounds__(256) void wino_fused_geo_kernel(int* __restrict__ g
     auto seg_off = [&](int k) { return k == 0 ? 0 : off1 + (k - 1) * rowslots; };
     const int nseg = len0 == WF_TILES ? 1 : 1 + (WF_TILES - len0 + TW - 1) / TW;
     const int total_slots = seg_off(nseg - 1) + 4 * (2 * seg_len(nseg - 1) + 2);
-    for (int s = tid; s < WF_SLOTS; s += 256) {
+    for (int pos = tid; pos < WF_SLOTS; pos += 256) {
+        // Raw-tile position pos holds logical slot s: the even slots first, then the odd ones.  Neighbouring tiles are two slots apart,
+        // so the lanes of a patch read (same patch column, consecutive tiles) then touch consecutive 16-B positions: conflict-free.
+        const int s = pos < WF_SLOTS / 2 ? 2 * pos : 2 * (pos - WF_SLOTS / 2) + 1;
         int pix = -1;
         if (s < total_slots) {
             const int k = s < off1 ? 0 : 1 + (s - off1) / rowslots;
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(256) void wino_fused_geo_kernel(int* __restrict__ g
             const int h = 2 * th - 1 + r, w = 2 * (k == 0 ? tw0 : 0) - 1 + col;
             if (R < RT && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) pix = (n * H + h) * W + w;
         }
-        rec[s] = pix;
+        rec[pos] = pix;
     }
     if (tid < WF_TILES) {
         int ex = 0, ey = 0, ez = 0, ew = 0;
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int pr = hh ? 3 - r : r;                       // upper half: patch rows 0, 1, 2; lower half: rows 3, 2, 1
-            pb[r] = lds0 + (unsigned)(WF_RAW_OFF + q * WF_QUAD + (tv ? (tileN.x + pr * tileN.y) * 16 : 0));
+            pb[r] = lds0 + (unsigned)(WF_RAW_OFF + q * WF_QUAD + (tv ? ((tileN.x + pr * tileN.y) >> 1) * 16 : 0));     // slot 0 and the pitch are even
 #pragma unroll
             for (int j = 0; j < 4; ++j) hi[r][j] = (((tileN.z >> pr) & 1) && ((tileN.z >> (4 + j)) & 1)) ? __builtin_inff() : 0.0f;
         }
@@ -274,7 +277,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(P[r][j]) : "v"(pb[r]), "n"(j * 16));
+            for (int j = 0; j < 4; ++j)          // patch column j = slot + j: odd slots live WF_SLOTS / 2 positions further
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(P[r][j]) : "v"(pb[r]), "n"((j & 1) * (WF_SLOTS / 2) * 16 + (j >> 1) * 16));
         if (XFORM) {
             asm volatile("ds_read_b128 %0, %1" : "=v"(sc) : "v"(ss_rd + (unsigned)(g * 32)));
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(sh) : "v"(ss_rd + (unsigned)(g * 32)), "n"(WF_MAXC * 4));
@@ -471,7 +475,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // packed weights and geometry records as wino_fused_kernel; what changes is who does what:
 //   MFMA    wave (wm = wave >> 1, wn = wave & 1): tiles 16 wm .., channels 32 wn ..; per plane one ds_read_b64 of A (lane (i, kq) takes
 //           channels 2 kq, 2 kq + 1 of tile row i = the k of its two MFMAs) and two of B, four MFMAs
-//   stage   thread (tile = lane, hh = wave & 1, q = (wave >> 1) & 1, half = wave >> 2): half a patch x 2 channels (8-B LDS accesses)
+//   stage   thread (hh = wave & 1, q = (wave >> 1) & 1, tile = 32 (wave >> 2) + lane / 2, channel pair = lane & 1): half a patch x 2
+//           channels (8-B LDS accesses)
 //   DMA     weight image: 4 pieces per wave; raw tile: waves 0-3 three pieces, waves 4-7 two; record: waves 0-3
 template <bool XFORM>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_fused8_kernel(WfArgs a) {
@@ -503,8 +508,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int c = tid; c < a.C; c += 512) { ss[c] = a.scale[c]; ss[WF_MAXC + c] = a.shift[c]; }
     }
 
-    // staging role
-    const int hh = wave & 1, q = (wave >> 1) & 1, half = wave >> 2;
+    // staging role: wave = (patch half hh, channel quad q, 32 tiles tg); lane = (tile, channel pair): the two lanes of a tile read /
+    // write the two 8-B halves of the same 16-B unit, so a 32-lane access group covers 16 consecutive units = all 64 banks once
+    const int hh = wave & 1, q = (wave >> 1) & 1, tile_l = 32 * (wave >> 2) + (lane >> 1), half = lane & 1;
     // raw-tile DMA pieces of this wave: piece ids P = 0 .. 19 (quad P / 10, 64 slots P % 10)
     const int np = wave < 4 ? 3 : 2, p_first = wave < 4 ? 3 * wave : 12 + 2 * (wave - 4);
     unsigned dof[3], pb[3];
@@ -527,7 +533,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
     auto read_tile = [&](int j) {
-        asm volatile("ds_read_b128 %0, %1" : "=v"(tileN) : "v"(lds0 + (unsigned)(WF_REC_OFF + (j & 1) * WF_REC_BYTES + WF_SLOTS * 4 + lane * 16)));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(tileN) : "v"(lds0 + (unsigned)(WF_REC_OFF + (j & 1) * WF_REC_BYTES + WF_SLOTS * 4 + tile_l * 16)));
     };
 #define WF8_TIE_SLOTS() asm volatile("" : "+v"(recN[0]), "+v"(recN[1]), "+v"(recN[2]))
 #define WF8_TIE_TILE() asm volatile("" : "+v"(tileN))
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int pr = hh ? 3 - r : r;
-            pb[r] = lds0 + (unsigned)(WF_RAW_OFF + q * WF_QUAD + half * 8 + (tv ? (tileN.x + pr * tileN.y) * 16 : 0));
+            pb[r] = lds0 + (unsigned)(WF_RAW_OFF + q * WF_QUAD + half * 8 + (tv ? ((tileN.x + pr * tileN.y) >> 1) * 16 : 0));
 #pragma unroll
             for (int j = 0; j < 4; ++j) hi[r][j] = (((tileN.z >> pr) & 1) && ((tileN.z >> (4 + j)) & 1)) ? __builtin_inff() : 0.0f;
         }
@@ -570,7 +576,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(P[r][j]) : "v"(pb[r]), "n"(j * 16));
+            for (int j = 0; j < 4; ++j)
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(P[r][j]) : "v"(pb[r]), "n"((j & 1) * (WF_SLOTS / 2) * 16 + (j >> 1) * 16));
         if (XFORM) {
             asm volatile("ds_read_b64 %0, %1" : "=v"(sc) : "v"(ss_rd + (unsigned)(g * 32)));
             asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(sh) : "v"(ss_rd + (unsigned)(g * 32)), "n"(WF_MAXC * 4));
@@ -587,7 +594,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         return f;
     };
     const float ysign = hh ? -1.f : 1.f;
-    const unsigned wr_lane = (unsigned)(lane * 32 + ((q ^ ((lane >> 3) & 1)) * 16) + half * 8);
+    const unsigned wr_lane = (unsigned)(tile_l * 32 + ((q ^ ((tile_l >> 3) & 1)) * 16) + half * 8);
     const unsigned x_wr = lds0 + (unsigned)(WF_A_OFF + (hh ? 12 : 0) * WF_PLANE) + wr_lane;
     const unsigned y_wr = lds0 + (unsigned)(WF_A_OFF + (hh ? 8 : 4) * WF_PLANE) + wr_lane;
     auto rows_of = [&](int j) {
