@@ -105,6 +105,7 @@ class Engine:
         # grid of the persistent fused Winograd kernel: 0 = one block per CU; a block fills its CU (LDS, registers) for the whole
         # launch, so a smaller grid leaves CUs to the tail / weight-gradient streams that run beside the backbone
         self._wf_blocks = int(os.environ.get('SSD_WF_BLOCKS', '0'))
+        self._fused_min = int(os.environ.get('SSD_FUSED_MIN', '70'))      # smallest map side that runs on the fused Winograd kernel
 
     # ------------------------------------------------------------------------------------------------ helpers
     def _weight(self, spec):
@@ -222,7 +223,7 @@ class Engine:
         if self.bf16 or c.is_head or os.environ.get('SSD_NO_FUSED_WINOGRAD') == '1':
             return False
         return (c.k == 3 and c.stride == 1 and c.pad == 1 and c.cin % 16 == 0 and 32 <= c.cin <= 512 and c.cout % 64 == 0
-                and min(g['hi'], g['wi']) >= 70 and N * g['hi'] * g['wi'] * max(c.cin * 4, c.cout) < (1 << 31)
+                and min(g['hi'], g['wi']) >= self._fused_min and N * g['hi'] * g['wi'] * max(c.cin * 4, c.cout) < (1 << 31)
                 and N * ((g['hi'] + 1) // 2) < 65536)
 
     def _patch_ok(self, i, N, geo):
