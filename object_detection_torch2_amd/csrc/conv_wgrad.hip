@@ -370,12 +370,17 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     }
 }
 
-__global__ void colsum_final_kernel(const float* __restrict__ partial, int MB, int C, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int MB, int C, float* __restrict__ out) {
+    // 64 channels x 4 row lanes per block; fixed order: lane k sums rows k, k + 4, .. in fp64, then lanes 0 .. 3 in order
+    __shared__ double red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     double s = 0.0;
-    for (int r = 0; r < MB; ++r) s += (double)partial[((size_t)r * C + c) * 2];
-    out[c] = (float)s;
+    if (c < C)
+        for (int r = rl; r < MB; r += 4) s += (double)partial[((size_t)r * C + c) * 2];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) out[c] = (float)(((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl]);
 }
 
 // ---- Winograd F(2x2,3x3) weight gradient (3x3 / stride 1 / pad 1 layers): dU[xi] = sum_t dM[xi][t]^T V[xi][t], 2.25x fewer flops ----
@@ -541,7 +546,7 @@ int ssdhip_conv2d_wgrad(const ssdhip_wgrad_params* p, void* stream) {
         hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(p->Cout, 64), MB), dim3(256), 0, st, p->dy, (long long)p->dy_batch_stride,
                            a.HoWo, (int64_t)a.M, p->Cout, p->dy_row, rows_per_block, partial);
         SSDHIP_CHECK_LAUNCH();
-        hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(p->Cout, 64)), dim3(64), 0, st, partial, MB, p->Cout, p->dbias);
+        hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(p->Cout, 64)), dim3(256), 0, st, partial, MB, p->Cout, p->dbias);
         SSDHIP_CHECK_LAUNCH();
     }
     return SSDHIP_OK;
@@ -605,7 +610,7 @@ int ssdhip_conv2d_wgrad_winograd(const ssdhip_wgrad_params* p, void* stream) {
         hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(p->Cout, 64), MB), dim3(256), 0, st, p->dy, (long long)p->dy_batch_stride,
                            p->Ho * p->Wo, (int64_t)M, p->Cout, p->dy_row, rows_per_block, partial);
         SSDHIP_CHECK_LAUNCH();
-        hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(p->Cout, 64)), dim3(64), 0, st, partial, MB, p->Cout, p->dbias);
+        hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(p->Cout, 64)), dim3(256), 0, st, partial, MB, p->Cout, p->dbias);
         SSDHIP_CHECK_LAUNCH();
     }
     return SSDHIP_OK;
