@@ -99,14 +99,16 @@ __device__ __forceinline__ float wino_u(const float* __restrict__ g9, int xi) {
 }
 
 // OIHW (Cout, Cin, 3, 3) -> [channel tile nb][K-step g][xi][row][physical 16-B chunk][4]: the B image of (nb, g) as it lies in LDS
-__global__ void wino_fused_pack_kernel(const float* __restrict__ w, float* __restrict__ upk, int Cout, int Cin) {
+// perm (the 8-wave kernel's order): row 16 c + i of a 32-row group holds output channel 2 i + c, so that the two channels a lane of that
+// kernel owns (MFMA column i of its two 16-column groups) are neighbours in memory: 8-B stores, 128 B per 16 lanes
+__global__ void wino_fused_pack_kernel(const float* __restrict__ w, float* __restrict__ upk, int Cout, int Cin, int perm) {
     const int64_t total = (int64_t)16 * Cout * Cin;
     const int KT = Cin / WF_BK;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int e = (int)(i & 3), chunk = (int)((i >> 2) & 1), row = (int)((i >> 3) & 63), xi = (int)((i >> 9) & 15);
         const int64_t rest = i >> 13;
         const int g = (int)(rest % KT), nb = (int)(rest / KT);
-        const int co = nb * 64 + row, c = WF_BK * g + 4 * (chunk ^ ((row >> 3) & 1)) + e;
+        const int co = nb * 64 + (perm ? (row & 32) + 2 * (row & 15) + ((row >> 4) & 1) : row), c = WF_BK * g + 4 * (chunk ^ ((row >> 3) & 1)) + e;
         const float u = wino_u(w + ((size_t)co * Cin + c) * 9, xi);
         upk[i] = xi >= 12 ? -u : u;          // the kernel's A image holds -V in planes 12..15 (see rows_of)
     }
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 //   stage   thread (hh = wave & 1, q = (wave >> 1) & 1, tile = 32 (wave >> 2) + lane / 2, channel pair = lane & 1): half a patch x 2
 //           channels (8-B LDS accesses)
 //   DMA     weight image: 4 pieces per wave; raw tile: waves 0-3 three pieces, waves 4-7 two; record: waves 0-3
-template <bool XFORM>
+template <bool XFORM, int ABL = 0>       // ABL: timing-only ablations (probe builds; wrong results): 1 no raw-tile DMA, 2 no weight DMA, 4 no transform, 8 no stores
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_fused8_kernel(WfArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -646,8 +648,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned f_lo = (unsigned)(li * 32 + ((kq * 8) ^ (((li >> 3) & 1) * 16)));
     const unsigned a_rd = lds0 + (unsigned)(WF_A_OFF + 16 * wm * 32) + f_lo;
     const unsigned b_rd = lds0 + (unsigned)(WF_B_OFF + 32 * wn * 32) + f_lo;
-    const int co0 = n0 + 32 * wn + li;
-    const float bv0 = a.bias ? a.bias[co0] : 0.f, bv1 = a.bias ? a.bias[co0 + 16] : 0.f;
+    const int co0 = n0 + 32 * wn + 2 * li;                 // this lane's two output channels: co0 (column group 0), co0 + 1 (group 1)
+    const float bv0 = a.bias ? a.bias[co0] : 0.f, bv1 = a.bias ? a.bias[co0 + 1] : 0.f;
     const int WC = a.W * a.Cout;
 
 #pragma clang loop unroll(disable)
@@ -678,7 +680,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fb1[c ^ 1]) : "v"(bb), "n"((p + 1) * WF_PLANE + 512));
                 }
                 if (p == 0) {
-                    dma_b(g1);
+                    if (!(ABL & 2)) dma_b(g1);
                     if (g == 0) dma_rec(jn, j + 1);
                     read_patch(g1);
                     if (g == KT - 3) read_slots(j + 1);
@@ -691,7 +693,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     WF8_TIE_SLOTS();
                     WF8_TIE_TILE();
                     __builtin_amdgcn_s_barrier();
-                    dma_raw(g2);
+                    if (!(ABL & 1)) dma_raw(g2);
                 } else if (p < 15) {
                     asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa[c]), "+v"(fb0[c]), "+v"(fb1[c]));
                 } else {
@@ -702,9 +704,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].x, fb1[c].x, acc[p][1], 0, 0, 0);
                 acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].y, fb0[c].y, acc[p][0], 0, 0, 0);
                 acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].y, fb1[c].y, acc[p][1], 0, 0, 0);
-                if (p >= 2 && p < 6) rows_of(p - 2);
-                if (p == 6) planes_of(0, nxt);
-                if (p == 7) planes_of(1, nxt);
+                if (p >= 2 && p < 6 && !(ABL & 4)) rows_of(p - 2);
+                if (p == 6 && !(ABL & 4)) planes_of(0, nxt);
+                if (p == 7 && !(ABL & 4)) planes_of(1, nxt);
                 __builtin_amdgcn_sched_barrier(0);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -714,7 +716,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (g == KT - 2) adopt_tile();
         }
 
-        // ---- output transform: per (channel group cg, register e): tile = 16 wm + 4 (lane >> 4) + e, channel = co0 + 16 cg
+        // ---- output transform: per register e: tile = 16 wm + 4 (lane >> 4) + e, channels co0, co0 + 1 (one 8-B store per pixel)
         const int mb = mb0 + j * mbstep;
         const char* rec = lds + WF_REC_OFF + (j & 1) * WF_REC_BYTES + WF_SLOTS * 4;
         float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
@@ -722,6 +724,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int e = 0; e < 4; ++e) {
             const int i = 16 * wm + 4 * kq + e;
             const int2 ent = *reinterpret_cast<const int2*>(rec + i * 16 + 8);
+            float y[2][2][2];                 // [channel group][output row][output column]
 #pragma unroll
             for (int cg = 0; cg < 2; ++cg) {
                 float r[2][4];
@@ -731,19 +734,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     r[1][jj] = (acc[4 + jj][cg][e] - acc[8 + jj][cg][e]) - acc[12 + jj][cg][e];
                 }
                 const float bv = cg ? bv1 : bv0;
-                float* zp = a.z + (size_t)ent.y * a.Cout + co0 + 16 * cg;
 #pragma unroll
                 for (int aa = 0; aa < 2; ++aa) {
-                    const float y0 = ((r[aa][0] + r[aa][1]) + r[aa][2]) + bv;
-                    const float y1 = ((r[aa][1] - r[aa][2]) - r[aa][3]) + bv;
-                    const bool rowok = ((ent.x >> 8) & 1) && (aa == 0 || ((ent.x >> 9) & 1));
-                    if (rowok) {
-                        zp[aa * WC] = y0;
-                        s1[cg] += y0; s2[cg] += y0 * y0;
-                        if ((ent.x >> 10) & 1) {
-                            zp[aa * WC + a.Cout] = y1;
-                            s1[cg] += y1; s2[cg] += y1 * y1;
-                        }
+                    y[cg][aa][0] = ((r[aa][0] + r[aa][1]) + r[aa][2]) + bv;
+                    y[cg][aa][1] = ((r[aa][1] - r[aa][2]) - r[aa][3]) + bv;
+                }
+            }
+            float* zp = a.z + (size_t)ent.y * a.Cout + co0;
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa) {
+                const bool rowok = ((ent.x >> 8) & 1) && (aa == 0 || ((ent.x >> 9) & 1));
+                if (rowok) {
+                    if (!(ABL & 8)) *reinterpret_cast<float2*>(zp + aa * WC) = make_float2(y[0][aa][0], y[1][aa][0]);
+                    s1[0] += y[0][aa][0]; s2[0] += y[0][aa][0] * y[0][aa][0];
+                    s1[1] += y[1][aa][0]; s2[1] += y[1][aa][0] * y[1][aa][0];
+                    if ((ent.x >> 10) & 1) {
+                        if (!(ABL & 8)) *reinterpret_cast<float2*>(zp + aa * WC + a.Cout) = make_float2(y[0][aa][1], y[1][aa][1]);
+                        s1[0] += y[0][aa][1]; s2[0] += y[0][aa][1] * y[0][aa][1];
+                        s1[1] += y[1][aa][1]; s2[1] += y[1][aa][1] * y[1][aa][1];
                     }
                 }
             }
@@ -756,8 +764,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 s1[cg] += __shfl_xor(s1[cg], 16, 64); s1[cg] += __shfl_xor(s1[cg], 32, 64);
                 s2[cg] += __shfl_xor(s2[cg], 16, 64); s2[cg] += __shfl_xor(s2[cg], 32, 64);
                 if (lane < 16) {
-                    red[(wm * 64 + 32 * wn + 16 * cg + lane) * 2] = s1[cg];
-                    red[(wm * 64 + 32 * wn + 16 * cg + lane) * 2 + 1] = s2[cg];
+                    red[(wm * 64 + 32 * wn + 2 * lane + cg) * 2] = s1[cg];
+                    red[(wm * 64 + 32 * wn + 2 * lane + cg) * 2 + 1] = s2[cg];
                 }
             }
             __syncthreads();
@@ -789,7 +797,11 @@ int ssdhip_wino_fused_pack(const float* w_oihw, float* upk, int Cout, int Cin, v
     const int64_t total = (int64_t)16 * Cout * Cin;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(wino_fused_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, upk, Cout, Cin);
+    int perm = 1;
+#ifdef SSDHIP_PROBES
+    if (const char* e = getenv("SSDHIP_WF8"); e && atoi(e) == 0) perm = 0;      // the 4-wave probe kernel keeps rows = channels
+#endif
+    hipLaunchKernelGGL(wino_fused_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, upk, Cout, Cin, perm);
     SSDHIP_CHECK_LAUNCH();
     return SSDHIP_OK;
 }
@@ -881,6 +893,11 @@ int ssdhip_wino_fused_conv(const float* x, const float* upk, const float* bias, 
     // The library launches the 8-wave form (6-15 % faster on every layer: scripts/wf_bench.py with SSDHIP_WF8=0 / 1,
     // profiles/r02_t_*); the 4-wave form it grew out of and its timing-only ablations exist in probe builds only.
 #ifdef SSDHIP_PROBES
+#define WF8_ABL_CASE(k) case k: { static DeviceOnce once; if (const int d = once.pending(); d != DeviceOnce::kDone) { \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused8_kernel<true, k>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS); once.mark(d); } \
+        hipLaunchKernelGGL((wino_fused8_kernel<true, k>), grid, dim3(512), WF_LDS, st, a); SSDHIP_CHECK_LAUNCH(); return a.MB; }
+    if (const char* e8 = getenv("SSDHIP_WF8_ABL"); e8 && in_scale) switch (atoi(e8)) { WF8_ABL_CASE(1) WF8_ABL_CASE(2) WF8_ABL_CASE(3) WF8_ABL_CASE(4) WF8_ABL_CASE(7) WF8_ABL_CASE(8) default: break; }
+#undef WF8_ABL_CASE
     if (const char* e = getenv("SSDHIP_WF8"); e && atoi(e) == 0) {
         if (in_scale) hipLaunchKernelGGL(wino_fused_kernel<true>, grid, block, WF_LDS, st, a);
         else hipLaunchKernelGGL(wino_fused_kernel<false>, grid, block, WF_LDS, st, a);

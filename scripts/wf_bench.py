@@ -41,6 +41,11 @@ for name, H, cin, cout in L:
         ba, ma = timeit(lambda: ops.wino_fused_conv(x, w, b, in_scale=sc, in_shift=sh, want_stats=True, upk=upk))
         del os.environ['SSDHIP_WF_BAND']
         print(f'    band {bd}: min {ba:7.3f} med {ma:7.3f} ms ({wino / ma / 1e9:6.1f} TF executed)', flush=True)
+    for abl in [int(v) for v in os.environ.get('ABLS8', '').split(',') if v]:
+        os.environ['SSDHIP_WF8_ABL'] = str(abl)
+        ba, ma = timeit(lambda: ops.wino_fused_conv(x, w, b, in_scale=sc, in_shift=sh, want_stats=True, upk=upk))
+        del os.environ['SSDHIP_WF8_ABL']
+        print(f'    8-wave ablation {abl}: med {ma:7.3f} ms ({wino / ma / 1e9:6.1f} TF executed)', flush=True)
     for abl in [int(v) for v in os.environ.get('ABLS', '').split(',') if v]:
         os.environ['SSDHIP_WF_ABL'] = str(abl)
         ba, ma = timeit(lambda: ops.wino_fused_conv(x, w, b, in_scale=sc, in_shift=sh, want_stats=True, upk=upk))
