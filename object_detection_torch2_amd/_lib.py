@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libssdhip.so')
 if os.environ.get('SSDHIP_PROBES') == '1':
     # measurement scripts only (scripts/*_probe.py, *_bench.py): the probe build of the same sources (`make -C csrc probes`), which
     # also holds the A/B and timing-only ablation kernels the product library refuses (tile codes >= 1,000,000)
-    LIB_PATH = os.path.join(_HERE, 'lib', 'libssdhip_probes.so')
+    LIB_PATH = os.path.join(_HERE, 'lib', os.environ.get('SSDHIP_PROBE_LIB', 'libssdhip_probes.so'))      # SSDHIP_PROBE_LIB: an A/B build of the probe library
 
 OK, EINVAL, ELAUNCH, ENOSUP = 0, -1, -2, -3
 

@@ -480,6 +480,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 //   stage   thread (hh = wave & 1, q = (wave >> 1) & 1, tile = 32 (wave >> 2) + lane / 2, channel pair = lane & 1): half a patch x 2
 //           channels (8-B LDS accesses)
 //   DMA     weight image: 4 pieces per wave; raw tile: waves 0-3 three pieces, waves 4-7 two; record: waves 0-3
+#ifndef WF8_MIDP
+#define WF8_MIDP 1      // plane slot of the mid-step barrier + raw-tile refill (A/B: -DWF8_MIDP=2 / 3)
+#endif
 template <bool XFORM, int ABL = 0>       // ABL: timing-only ablations (probe builds; wrong results): 1 no raw-tile DMA, 2 no weight DMA, 4 no transform, 8 no stores
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_fused8_kernel(WfArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -692,10 +695,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     WF8_TIE_P();
                     WF8_TIE_SLOTS();
                     WF8_TIE_TILE();
-                    __builtin_amdgcn_s_barrier();
-                    if (!(ABL & 1)) dma_raw(g2);
+                    if (WF8_MIDP == 1) { __builtin_amdgcn_s_barrier(); if (!(ABL & 1)) dma_raw(g2); }
                 } else if (p < 15) {
                     asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa[c]), "+v"(fb0[c]), "+v"(fb1[c]));
+                    if (p == WF8_MIDP) { __builtin_amdgcn_s_barrier(); if (!(ABL & 1)) dma_raw(g2); }     // every thread has its patch: refill the raw tile
                 } else {
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[c]), "+v"(fb0[c]), "+v"(fb1[c]));
                 }
