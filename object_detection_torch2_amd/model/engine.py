@@ -104,7 +104,11 @@ class Engine:
         self.prof = None       # list: when set, forward conv launches are bracketed by events (bench.py roofline leg)
         # grid of the persistent fused Winograd kernel: 0 = one block per CU; a block fills its CU (LDS, registers) for the whole
         # launch, so a smaller grid leaves CUs to the tail / weight-gradient streams that run beside the backbone
-        self._wf_blocks = int(os.environ.get('SSD_WF_BLOCKS', '0'))
+        # SSD_WF_BLOCKS unset: 224 of the 256 CUs while the backbone runs beside the tail's streams (the small dependent launches of the
+        # tail then never queue behind a whole persistent launch: 12.35-12.46 vs 12.56-12.63 ms per step; 240 or 192 are worse), all
+        # 256 when it runs alone
+        self._wf_blocks_env = os.environ.get('SSD_WF_BLOCKS')
+        self._wf_blocks = int(self._wf_blocks_env) if self._wf_blocks_env is not None else 0
         self._fused_min = int(os.environ.get('SSD_FUSED_MIN', '70'))      # smallest map side that runs on the fused Winograd kernel
 
     # ------------------------------------------------------------------------------------------------ helpers
@@ -448,6 +452,8 @@ class Engine:
         # launches that cannot fill the chip).  Only two backbone outputs have consumers outside the backbone stream -- the inputs
         # of det_4_3 and of conv_6_1 (forward and weight gradient): those stages wait for the events their readers leave in _readers.
         bb = None if (self.single_stream or self.tail_start == 0) else self._side_stream(dev, which=2)
+        if self._wf_blocks_env is None:
+            self._wf_blocks = 224 if (bb is not None and self.tail_start < len(self.stages)) else 0
         entry = main.record_event() if fork.side_stream is not None else None
         if fork.side_stream is not None:
             fork.side_stream.wait_event(entry)               # `out` may reuse memory that step i's loss kernels still read
