@@ -328,6 +328,8 @@ def main():
             # profiles/r01_o_*) is 0.66-0.72 ms.  So the figure that rocprofv3 can confirm is taken over three more steps with
             # the streams serialised (same launches, same order per stream); the timed-region event figures stay in the line
             # as `timed_region`.
+            frozen_grid = eng._wf_blocks_env
+            eng._wf_blocks_env = str(eng._wf_blocks)      # same grid as in the timed region (224 of 256 CUs beside the tail's streams)
             eng.single_stream = True
             step()                           # one unrecorded step to leave the pipelined regime
             torch.cuda.synchronize()
@@ -337,6 +339,7 @@ def main():
             torch.cuda.synchronize()
             ex = aggregate(eng.prof).get(name)
             eng.single_stream = False
+            eng._wf_blocks_env = frozen_grid
             if ex:
                 ach_x = ex['flops'] / (ex['ms'] * 1e-3) / 1e12
                 roof['timed_region'] = dict(achieved=roof['achieved'], frac=roof['frac'], avg_launch_ms=roof['avg_launch_ms'], launches=roof['launches'],
@@ -350,6 +353,12 @@ def main():
             dq = roof['achieved'] * a['direct'] / a['flops']
             roof['direct_equivalent'] = dict(achieved=round(dq, 2), frac=round(dq / peak, 4),
                                              algorithmic_flop_per_launch=round(a['direct'] / a['n']))
+        if name.startswith('wino_fused8_kernel') and getattr(eng, '_wf_blocks', 0):
+            # the persistent backbone kernels take 224 of the 256 CUs while the tail's streams run beside them (0.15-0.2 ms per step);
+            # `frac` stays priced against the whole chip's peak, this field prices the same launches against the CUs they occupy
+            roof['cus_used'] = eng._wf_blocks
+            roof['frac_of_cus_used'] = round(roof['frac'] * 256.0 / eng._wf_blocks, 4)
+            notes.append(f'the kernel is launched on {eng._wf_blocks} of the 256 CUs (the rest is left to the concurrent tail streams)')
         roof['note'] = '; '.join(notes) if notes else None
     eng.prof = None
 
