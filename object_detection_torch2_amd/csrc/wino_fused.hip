@@ -707,9 +707,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].x, fb1[c].x, acc[p][1], 0, 0, 0);
                 acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].y, fb0[c].y, acc[p][0], 0, 0, 0);
                 acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].y, fb1[c].y, acc[p][1], 0, 0, 0);
-                if (p >= 2 && p < 6 && !(ABL & 4)) rows_of(p - 2);
-                if (p == 6 && !(ABL & 4)) planes_of(0, nxt);
-                if (p == 7 && !(ABL & 4)) planes_of(1, nxt);
+                if (p >= 2 && p < 6 && !(ABL & 4) && !(ABL & 32)) rows_of(p - 2);        // 32: no row pass (activation + B^T d)
+                if (p == 6 && !(ABL & 4) && !(ABL & 16)) planes_of(0, nxt);                // 16: no column pass / A-image stores
+                if (p == 7 && !(ABL & 4) && !(ABL & 16)) planes_of(1, nxt);
                 __builtin_amdgcn_sched_barrier(0);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -899,7 +899,7 @@ int ssdhip_wino_fused_conv(const float* x, const float* upk, const float* bias, 
 #define WF8_ABL_CASE(k) case k: { static DeviceOnce once; if (const int d = once.pending(); d != DeviceOnce::kDone) { \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused8_kernel<true, k>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS); once.mark(d); } \
         hipLaunchKernelGGL((wino_fused8_kernel<true, k>), grid, dim3(512), WF_LDS, st, a); SSDHIP_CHECK_LAUNCH(); return a.MB; }
-    if (const char* e8 = getenv("SSDHIP_WF8_ABL"); e8 && in_scale) switch (atoi(e8)) { WF8_ABL_CASE(1) WF8_ABL_CASE(2) WF8_ABL_CASE(3) WF8_ABL_CASE(4) WF8_ABL_CASE(7) WF8_ABL_CASE(8) default: break; }
+    if (const char* e8 = getenv("SSDHIP_WF8_ABL"); e8 && in_scale) switch (atoi(e8)) { WF8_ABL_CASE(1) WF8_ABL_CASE(2) WF8_ABL_CASE(3) WF8_ABL_CASE(4) WF8_ABL_CASE(7) WF8_ABL_CASE(8) WF8_ABL_CASE(16) WF8_ABL_CASE(32) default: break; }
 #undef WF8_ABL_CASE
     if (const char* e = getenv("SSDHIP_WF8"); e && atoi(e) == 0) {
         if (in_scale) hipLaunchKernelGGL(wino_fused_kernel<true>, grid, block, WF_LDS, st, a);
