@@ -7,6 +7,7 @@ from object_detection_torch2_amd.model import SSD
 from object_detection_torch2_amd.optim import FusedAdam
 dev = 'cuda:0'
 net = SSD(21).to(dev); df = net.default_bboxes.to(dev)
+net.set_compute_dtype(os.environ.get('DTYPE', 'fp32'))
 opt = FusedAdam(net.train_params(), lr=1e-3, weight_decay=5e-4, on_step=net.hip_weights_changed)
 ims = torch.from_numpy(synth.images(1, 32)).to(dev); tgs = torch.from_numpy(synth.targets(2, 32, g_max=8)).to(dev)
 torch.cuda.synchronize(); ev = torch.cuda.current_stream().record_event()
