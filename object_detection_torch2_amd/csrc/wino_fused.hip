@@ -99,16 +99,29 @@ __device__ __forceinline__ float wino_u(const float* __restrict__ g9, int xi) {
 }
 
 // OIHW (Cout, Cin, 3, 3) -> [channel tile nb][K-step g][xi][row][physical 16-B chunk][4]: the B image of (nb, g) as it lies in LDS
-// perm (the 8-wave kernel's order): row 16 c + i of a 32-row group holds output channel 2 i + c, so that the two channels a lane of that
-// kernel owns (MFMA column i of its two 16-column groups) are neighbours in memory: 8-B stores, 128 B per 16 lanes
+// perm = the 8-wave kernel's image (see the loop): a lane of that kernel owns MFMA column r of two 16-column groups = the neighbouring
+// output channels 2 r, 2 r + 1 (8-B stores, 128 B per 16 lanes) and fetches their operands with one 16-B read
 __global__ void wino_fused_pack_kernel(const float* __restrict__ w, float* __restrict__ upk, int Cout, int Cin, int perm) {
     const int64_t total = (int64_t)16 * Cout * Cin;
     const int KT = Cin / WF_BK;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int e = (int)(i & 3), chunk = (int)((i >> 2) & 1), row = (int)((i >> 3) & 63), xi = (int)((i >> 9) & 15);
+        const int xi = (int)((i >> 9) & 15);
         const int64_t rest = i >> 13;
         const int g = (int)(rest % KT), nb = (int)(rest / KT);
-        const int co = nb * 64 + (perm ? (row & 32) + 2 * (row & 15) + ((row >> 4) & 1) : row), c = WF_BK * g + 4 * (chunk ^ ((row >> 3) & 1)) + e;
+        int co, c;
+        if (perm) {
+            // 8-wave kernel: plane = [channel half wn][row r of 16][16-B unit][4]: unit u of row r holds, for k-quarter kq = u ^ f(r), the
+            // channel pairs (2 kq, 2 kq + 1) of output channels 32 wn + 2 r and + 1 -- one ds_read_b128 feeds a lane's four MFMAs;
+            // f = 0, 3, 2, 1 for r / 4 = 0 .. 3 makes every 16-lane group of that read hit 16 different bank units
+            const int e = (int)(i & 3), unit = (int)((i >> 2) & 3), r = (int)((i >> 4) & 15), wn = (int)((i >> 8) & 1);
+            const int kq = unit ^ ((4 - (r >> 2)) & 3);
+            co = nb * 64 + 32 * wn + 2 * r + (e >> 1);
+            c = WF_BK * g + 2 * kq + (e & 1);
+        } else {
+            const int e = (int)(i & 3), chunk = (int)((i >> 2) & 1), row = (int)((i >> 3) & 63);
+            co = nb * 64 + row;
+            c = WF_BK * g + 4 * (chunk ^ ((row >> 3) & 1)) + e;
+        }
         const float u = wino_u(w + ((size_t)co * Cin + c) * 9, xi);
         upk[i] = xi >= 12 ? -u : u;          // the kernel's A image holds -V in planes 12..15 (see rows_of)
     }
@@ -650,7 +663,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int li = lane & 15, kq = lane >> 4;
     const unsigned f_lo = (unsigned)(li * 32 + ((kq * 8) ^ (((li >> 3) & 1) * 16)));
     const unsigned a_rd = lds0 + (unsigned)(WF_A_OFF + 16 * wm * 32) + f_lo;
-    const unsigned b_rd = lds0 + (unsigned)(WF_B_OFF + 32 * wn * 32) + f_lo;
+    const unsigned b_rd = lds0 + (unsigned)(WF_B_OFF + wn * 1024 + li * 64 + ((kq ^ ((4 - (li >> 2)) & 3)) * 16));
     const int co0 = n0 + 32 * wn + 2 * li;                 // this lane's two output channels: co0 (column group 0), co0 + 1 (group 1)
     const float bv0 = a.bias ? a.bias[co0] : 0.f, bv1 = a.bias ? a.bias[co0 + 1] : 0.f;
     const int WC = a.W * a.Cout;
@@ -670,17 +683,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const unsigned cur = (unsigned)(g & 1) * WF_OPER, nxt = cur ^ WF_OPER;
             const unsigned ab = a_rd + cur, bb = b_rd + cur;
             const int g1 = g + 1 < KT ? g + 1 : 0, g2 = g + 2 < KT ? g + 2 : g + 2 - KT;
-            f32x2 fa[2], fb0[2], fb1[2];
+            f32x2 fa[2];
+            f32x4 fb[2];             // (channel 2 r: k-pair) (channel 2 r + 1: k-pair)
             asm volatile("ds_read_b64 %0, %1" : "=v"(fa[0]) : "v"(ab));
-            asm volatile("ds_read_b64 %0, %1" : "=v"(fb0[0]) : "v"(bb));
-            asm volatile("ds_read_b64 %0, %1 offset:512" : "=v"(fb1[0]) : "v"(bb));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(fb[0]) : "v"(bb));
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
                 const int c = p & 1;
                 if (p < 15) {
                     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fa[c ^ 1]) : "v"(ab), "n"((p + 1) * WF_PLANE));
-                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fb0[c ^ 1]) : "v"(bb), "n"((p + 1) * WF_PLANE));
-                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fb1[c ^ 1]) : "v"(bb), "n"((p + 1) * WF_PLANE + 512));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[c ^ 1]) : "v"(bb), "n"((p + 1) * WF_PLANE));
                 }
                 if (p == 0) {
                     if (!(ABL & 2)) dma_b(g1);
@@ -689,24 +701,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     if (g == KT - 3) read_slots(j + 1);
                     if (g == KT - 2) read_tile(j + 1);
                     // this plane's three fragments were issued first: at most 15 newer reads may stay outstanding (4-bit field)
-                    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(fa[c]), "+v"(fb0[c]), "+v"(fb1[c]) : "n"(15));
+                    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fa[c]), "+v"(fb[c]) : "n"(15));
                 } else if (p == 1) {
-                    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa[c]), "+v"(fb0[c]), "+v"(fb1[c]));
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[c]), "+v"(fb[c]));
                     WF8_TIE_P();
                     WF8_TIE_SLOTS();
                     WF8_TIE_TILE();
                     if (WF8_MIDP == 1) { __builtin_amdgcn_s_barrier(); if (!(ABL & 1)) dma_raw(g2); }
                 } else if (p < 15) {
-                    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa[c]), "+v"(fb0[c]), "+v"(fb1[c]));
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[c]), "+v"(fb[c]));
                     if (p == WF8_MIDP) { __builtin_amdgcn_s_barrier(); if (!(ABL & 1)) dma_raw(g2); }     // every thread has its patch: refill the raw tile
                 } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[c]), "+v"(fb0[c]), "+v"(fb1[c]));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[c]), "+v"(fb[c]));
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].x, fb0[c].x, acc[p][0], 0, 0, 0);
-                acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].x, fb1[c].x, acc[p][1], 0, 0, 0);
-                acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].y, fb0[c].y, acc[p][0], 0, 0, 0);
-                acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].y, fb1[c].y, acc[p][1], 0, 0, 0);
+                acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].x, fb[c].x, acc[p][0], 0, 0, 0);
+                acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].x, fb[c].z, acc[p][1], 0, 0, 0);
+                acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].y, fb[c].y, acc[p][0], 0, 0, 0);
+                acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].y, fb[c].w, acc[p][1], 0, 0, 0);
                 if (p >= 2 && p < 6 && !(ABL & 4) && !(ABL & 32)) rows_of(p - 2);        // 32: no row pass (activation + B^T d)
                 if (p == 6 && !(ABL & 4) && !(ABL & 16)) planes_of(0, nxt);                // 16: no column pass / A-image stores
                 if (p == 7 && !(ABL & 4) && !(ABL & 16)) planes_of(1, nxt);
