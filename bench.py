@@ -415,8 +415,8 @@ def main():
         line = dict(metric=metric, value=round(value, 2), unit='images/sec', n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
                     scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
-                    config=dict(workload='SSD300 training batch=32/GPU, fp32, IoU-match thresh=0.25, hard-neg 3:1, Adam '
-                                         '(BASELINE configs[2]' + ('; data-parallel, RCCL grad all-reduce)' if world > 1 else ')'),
+                    config=dict(workload=f'SSD300 training batch={B}/GPU, fp32, IoU-match thresh=0.25, hard-neg 3:1, Adam '
+                                         '(BASELINE configs[2]' + (f'; data-parallel, {"RCCL" if dist.get_backend() == "nccl" else dist.get_backend()} grad all-reduce)' if world > 1 else ')'),
                                 global_batch=world * B, image='300x300x3', priors=8732, classes=21, parallelism=f'dp{world}',
                                 bn='train-mode batch statistics (reference never calls eval())', backbone='frozen VGG16-bn'),
                     conv_flop_roofline_frac=round(value / world * (gf_train if args.mode == 'train' else gf_fwd)
