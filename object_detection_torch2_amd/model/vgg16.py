@@ -306,15 +306,23 @@ class VGG16(nn.Module):
             raise RuntimeError('VGG16 backward called without a saved forward')
         head, lins = self._lin
         g = _lib.f32c(grad_out)
+        # data parallelism: the classifier stack's gradients are separate tensors (fc1 alone is 411 MB); each goes into the same
+        # asynchronous all-reduce hook as the feature gradients the moment its weight-gradient launch is enqueued, so the collectives
+        # travel while the rest of the backward computes; the engine's finish() (or wait_launched below) waits for all of them
+        hook = self._dist_hook
+        reduce_ = hook.launch if hook is not None else (lambda t: None)
         dw3, db3, da2 = lins[2].backward(lib, sv['a2'], g, True, self._ws)
+        reduce_(dw3); reduce_(db3)
         dz2 = torch.empty_like(da2)
         _lib.check(lib.ssdhip_relu_dropout(_lib.ptr(sv['z2']), _lib.ptr(da2), _lib.ptr(dz2), dz2.numel(), head[5].p, sv['keys'][1],
                                            int(sv['training']), _lib.stream()), 'relu+dropout backward')
         dw2, db2, da1 = lins[1].backward(lib, sv['a1'], dz2, True, self._ws)
+        reduce_(dw2); reduce_(db2)
         dz1 = torch.empty_like(da1)
         _lib.check(lib.ssdhip_relu_dropout(_lib.ptr(sv['z1']), _lib.ptr(da1), _lib.ptr(dz1), dz1.numel(), head[2].p, sv['keys'][0],
                                            int(sv['training']), _lib.stream()), 'relu+dropout backward')
         dw1, db1, dflat = lins[0].backward(lib, sv['flat'], dz1, self._features_trainable, self._ws)
+        reduce_(dw1); reduce_(db1)
         head_grads = {id(head[0].weight): dw1, id(head[0].bias): db1, id(head[3].weight): dw2, id(head[3].bias): db2,
                       id(head[6].weight): dw3, id(head[6].bias): db3}
         feat_grads = {}
@@ -324,6 +332,8 @@ class VGG16(nn.Module):
             _lib.check(lib.ssdhip_nhwc_flatten(_lib.ptr(dflat), _lib.ptr(dmap), N, h, w, C, 1, _lib.stream()), 'flatten backward')
             grads, params = self._engine().backward(dmap)
             feat_grads = {id(p): gr.clone() for p, gr in zip(params, grads)}    # views of the engine's flat buffer: detach from it
+        if hook is not None:
+            hook.wait_launched()             # frozen features: nobody called finish(); otherwise nothing is left to wait for
         return [head_grads.get(id(p), feat_grads.get(id(p))) for p in self._autograd_params()]
 
     def _autograd_params(self):

@@ -23,6 +23,9 @@ def init_from_env(backend=None):
     if os.environ.get('SSD_FORCE_DEVICE') is not None:      # rehearsal: every rank on the same device
         local = int(os.environ['SSD_FORCE_DEVICE'])
     if world > 1 and not dist.is_initialized():
+        # dmabuf IPC: on this driver RCCL's peer mappings (hipIpcGetMemHandle) fail in the legacy mode; must be in the environment
+        # before the first HIP call of the process, whichever entry point (bench.py, train.py under torchrun) got here
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -53,7 +56,7 @@ class GradAllReduce:
 
     def __init__(self, group=None, n_buckets=2, average=False):
         self.group, self.n_buckets, self.average = group, max(1, n_buckets), average
-        self._works, self._done_from = [], None
+        self._works, self._done_from, self._extra = [], None, []
 
     def bucket_ranges(self, n, lo=0):
         step = -(-(n - lo) // self.n_buckets)
@@ -71,15 +74,35 @@ class GradAllReduce:
         for a, b in self.bucket_ranges(hi, lo):
             self._works.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
+    def launch(self, t):
+        """Asynchronous all-reduce(sum) of one more final, contiguous gradient tensor that lives outside the engine's flat buffer (the
+        classifier stack of VGG16: 411 + 67 MB).  Large tensors travel as they are (one call each); the collective is ordered after the
+        kernels already enqueued on the current stream and is waited for by `wait_launched()` or the next `finish()`."""
+        if not self._active():
+            return
+        if not t.is_contiguous():
+            raise ValueError('GradAllReduce.launch: contiguous tensors only')
+        self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.average:
+            self._extra.append(t)
+
+    def wait_launched(self):
+        """Make the current stream wait for every collective launched so far (a no-op when finish() already did)."""
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if self.average and self._extra:
+            torch._foreach_mul_(self._extra, 1.0 / dist.get_world_size(self.group))
+        self._extra = []
+
     def finish(self, flat):
         if not self._active():
             return
         end = flat.numel() if self._done_from is None else self._done_from
         if end > 0:
             self._works.append(dist.all_reduce(flat[:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        for w in self._works:
-            w.wait()
-        self._works, self._done_from = [], None
+        self._done_from = None
+        self.wait_launched()
         if self.average:
             flat.mul_(1.0 / dist.get_world_size(self.group))
 
@@ -120,22 +143,42 @@ def broadcast_module(net, src=0, group=None):
 
 @torch.no_grad()
 def broadcast_optimizer_state(opt, src=0, group=None):
-    """Same for a resumed optimizer: Adam moments and step counts of rank `src` (FusedAdam.state_dict layout = torch's)."""
+    """Same for a resumed optimizer: Adam moments and step counts of rank `src` (FusedAdam.state_dict layout = torch's).
+    The typical caller is a resume where ONLY rank `src` loaded a checkpoint, so the other ranks have no state at all: the
+    sequence of collectives must not depend on what a rank happens to hold.  Every rank therefore first materialises zero
+    moments and step 0 for every parameter of the optimizer (what Adam itself would create lazily), then takes part in the same
+    two broadcasts: one flat message with all moments, one with all step counts."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    for g in opt.param_groups:
-        for p in g['params']:
-            st = opt.state.get(p)
-            if not st:
-                continue
-            for k in ('exp_avg', 'exp_avg_sq'):
-                if k in st:
-                    dist.broadcast(st[k], src=src, group=group)
-            mine = st.get('step', 0)
-            step = torch.tensor([float(mine)], device=p.device)
-            dist.broadcast(step, src=src, group=group)
-            st['step'] = torch.tensor(step.item()) if torch.is_tensor(mine) else int(step.item())
-    if hasattr(opt, 'invalidate'):
+    fused = hasattr(opt, 'invalidate')           # FusedAdam keeps `step` as a Python int, torch.optim.Adam as a float32 scalar tensor
+    params = [p for g in opt.param_groups for p in g['params']]
+    if not params:
+        return
+    moments = []
+    for p in params:
+        st = opt.state[p]                        # defaultdict: creates the empty record
+        for k in ('exp_avg', 'exp_avg_sq'):
+            if k not in st:
+                st[k] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            moments.append(st[k])
+        if 'step' not in st:
+            st['step'] = 0 if fused else torch.tensor(0.0, dtype=torch.float32)
+    by_dev = {}
+    for t in moments:
+        by_dev.setdefault((t.device, t.dtype), []).append(t)
+    for (_, _), ts in sorted(by_dev.items(), key=lambda kv: str(kv[0])):
+        flat = torch.cat([t.reshape(-1) for t in ts])
+        dist.broadcast(flat, src=src, group=group)
+        o = 0
+        for t in ts:
+            t.copy_(flat[o:o + t.numel()].view_as(t))
+            o += t.numel()
+    steps = torch.tensor([float(opt.state[p]['step']) for p in params], dtype=torch.float64, device=params[0].device)
+    dist.broadcast(steps, src=src, group=group)
+    for p, v in zip(params, steps.tolist()):
+        mine = opt.state[p]['step']
+        opt.state[p]['step'] = torch.tensor(v, dtype=mine.dtype, device=mine.device) if torch.is_tensor(mine) else int(v)
+    if fused:
         opt.invalidate()
 
 

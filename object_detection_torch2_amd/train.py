@@ -88,6 +88,7 @@ def main():
         net.to(device)
         if world > 1:
             parallel.broadcast_module(net)
+            net.dropout_seed = rank          # one seed on every rank would drop the same units in every shard of the global batch (correlated masks)
         defaults = None
     else:
         net = build_model(device, world, weights_path, Path(args.result_dir) / 'classification' / args.weights)
@@ -157,9 +158,6 @@ def main():
                 loss = net.loss(outputs=outputs, targets=gts, default_bboxes=defaults)
             cur = fetch()
             loss.backward()
-            if classify and world > 1:          # the engine's hook reduces the feature gradients; the classifier stack's are separate tensors
-                for prm in net._head().parameters():
-                    torch.distributed.all_reduce(prm.grad)
             optimizer.step()
             running += loss.detach()
         local_loss = running.item() / max(n_steps, 1)

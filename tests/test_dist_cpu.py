@@ -179,3 +179,89 @@ def test_attach_survives_finetune_backbone_in_both_orders():
     b.finetune_backbone()
     parallel.attach(b)
     assert b._engine().dist_hook is not None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# resume under data parallelism: only rank 0 loaded optimizer state; the other ranks hold none (the collective
+# sequence must not depend on what a rank happens to hold)
+# ---------------------------------------------------------------------------------------------------------------------
+def _opt_state_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from object_detection_torch2_amd import parallel
+    from object_detection_torch2_amd.optim import FusedAdam
+    parallel.init_from_env(backend='gloo')
+    torch.manual_seed(5)
+    lin = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+    out = []
+    # (a) stock torch.optim.Adam: rank 0 took three real steps (state: exp_avg, exp_avg_sq, step tensor), rank 1 none
+    opt = torch.optim.Adam(lin.parameters(), lr=1e-2)
+    if rank == 0:
+        for k in range(3):
+            opt.zero_grad()
+            lin(torch.full((2, 7), float(k + 1))).sum().backward()
+            opt.step()
+    parallel.broadcast_module(lin)
+    parallel.broadcast_optimizer_state(opt)
+    digest = torch.cat([opt.state[p][k].reshape(-1) for p in lin.parameters() for k in ('exp_avg', 'exp_avg_sq')] +
+                       [torch.stack([torch.as_tensor(float(opt.state[p]['step'])) for p in lin.parameters()])])
+    got = [torch.empty_like(digest) for _ in range(world)]
+    dist.all_gather(got, digest)
+    out.append(all(torch.equal(got[0], g) for g in got) and float(opt.state[next(lin.parameters())]['step']) == 3.0
+               and torch.is_tensor(opt.state[next(lin.parameters())]['step']) and digest.abs().sum().item() > 0)
+    # one more identical step on both ranks must keep them identical (the materialised state is a valid Adam state)
+    opt.zero_grad()
+    lin(torch.ones(2, 7)).sum().backward()
+    opt.step()
+    w = torch.cat([p.detach().reshape(-1) for p in lin.parameters()])
+    ws = [torch.empty_like(w) for _ in range(world)]
+    dist.all_gather(ws, w)
+    out.append(all(torch.equal(ws[0], x) for x in ws))
+    # (b) FusedAdam's layout (Python int step; step() itself needs a GPU, the state exchange does not)
+    fo = FusedAdam(lin.parameters(), lr=1e-3)
+    if rank == 0:
+        for i, p in enumerate(lin.parameters()):
+            fo.state[p] = dict(step=41, exp_avg=torch.full_like(p, 0.5 + i), exp_avg_sq=torch.full_like(p, 0.25 + i))
+    fo._plans = {0: 'stale'}
+    parallel.broadcast_optimizer_state(fo)
+    ok = fo._plans == {}
+    for i, p in enumerate(lin.parameters()):
+        st = fo.state[p]
+        ok = ok and st['step'] == 41 and isinstance(st['step'], int) and bool((st['exp_avg'] == 0.5 + i).all()) and bool((st['exp_avg_sq'] == 0.25 + i).all())
+    out.append(ok)
+    # (c) extra tensors through the hook (classifier stack of VGG16): launch() + wait_launched(), and through finish()
+    hook = parallel.GradAllReduce(n_buckets=2)
+    a, b, flat = torch.full((1000,), float(rank + 1)), torch.full((3, 5), float(10 * (rank + 1))), torch.full((64,), float(rank + 1))
+    hook.launch(a)
+    hook.wait_launched()
+    hook.launch(b)
+    hook.start(flat, 32, 64)
+    hook.finish(flat)
+    tot = sum(range(1, world + 1))
+    out.append(bool((a == tot).all()) and bool((b == 10 * tot).all()) and bool((flat == tot).all()) and hook._works == [])
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_optimizer_state_broadcast_when_only_rank0_has_state():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_opt_state_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out in res:
+        assert out == [True, True, True, True], (rank, out)
+
+
+def test_init_from_env_sets_dmabuf_ipc_before_any_gpu_call(monkeypatch):
+    """train.py under torch.distributed.run never went through bench.py's launcher, which was the only place that set
+    HSA_ENABLE_IPC_MODE_LEGACY=0 (RCCL peer mappings need dmabuf IPC on this driver)."""
+    import inspect
+    from object_detection_torch2_amd import parallel
+    src = inspect.getsource(parallel.init_from_env)
+    assert src.index('HSA_ENABLE_IPC_MODE_LEGACY') < src.index('is_available') < src.index('init_process_group')
