@@ -34,6 +34,8 @@ extern "C" {
 /* library / device probe (no reference equivalent) */
 int ssdhip_version(void);
 const char* ssdhip_last_error(void);
+/* compute units of the current device (256 on an MI355X in SPX mode); persistent grids and split-K targets are derived from it */
+int ssdhip_cu_count(void);
 
 /* ---- A9  SSD._get_default_bboxes (model/ssd.py:108-133) ------------------------------------------------
  * out: (P,4) fp32 rows [cx,cy,w,h]; HOST table maps[k] = {m, n, anchors}; computed in fp64, rounded once.
@@ -103,6 +105,23 @@ int ssdhip_winograd_output(const float* M, const float* bias, float* y, float* s
  * offset: element (n,h,w,co) at y[n*y_batch_stride + (h*W+w)*Cout + co]  (model/ssd.py:103-104)                          */
 int ssdhip_winograd_output_head(const float* M, const float* bias, float* y, int64_t y_batch_stride, int N, int H, int W, int Cout,
                                 int Cp, void* stream);
+
+/* ---- A3 (frozen 3x3 / stride 1 / pad 1 backbone layers, forward)  Winograd F(4x4,3x3), points (0, +-3/2, +-2/3, inf): 36 products per
+ * 4x4 output tile = 4x fewer MFMA flops than the direct form of nn.Conv2d (model/vgg16.py:33), 1.78x fewer than F(2x2,3x3).
+ * T = N*ceil(H/4)*ceil(W/4) tiles, Tp = T rounded up to row_pad (64 or 128 = the GEMM's m-tile).  V and M are (36, Tp, C) fp32 planes.
+ *   weight:  U (36, rows_pad, KP) = G g G^T per (co, ci) in fp64, rounded once, zero padded
+ *   input:   V = B^T d B of every 6x6 patch, producer BN scale/shift + ReLU fused on load (in_scale may be NULL), zero pad after it
+ *   GEMM:    ssdhip_conv2d_nhwc with N=36, Hi=Ho=1, Wi=Wo=Tp, R=S=1, w_img_stride = rows_pad*KP, rows_per_img = Tp
+ *   output:  y (N,H,W,Cout) = A^T m A + bias, BN partial sums (rows, Cout, 2); returns the number of partial rows
+ *            (= ssdhip_winograd4_stat_rows, for sizing the table)
+ * Per-layer error against an fp64 convolution: 1.1e-6 rms / 2.3e-6 max of the output scale (F(2x2): 4e-7 / 5e-7); csrc/winograd4.hip. */
+int ssdhip_winograd4_tiles(int N, int H, int W, int row_pad, int* T, int* Tp);
+int ssdhip_winograd4_weight(const float* w_oihw, float* U, int Cout, int Cin, int rows_pad, int KP, void* stream);
+int ssdhip_winograd4_input(const float* x, const float* in_scale, const float* in_shift, float* V, int N, int H, int W, int C, int Tp,
+                           void* stream);
+int ssdhip_winograd4_stat_rows(int N, int H, int W, int Cout);
+int ssdhip_winograd4_output(const float* M, const float* bias, float* y, float* stats, int N, int H, int W, int Cout, int Tp,
+                            void* stream);
 
 /* ---- A4  nn.BatchNorm2d, training=True (model/vgg16.py:34, model/ssd.py:62) -----------------------------
  * partial (MB,C,2) -> scale = gamma*rsqrt(var+eps), shift = beta-mean*scale (biased var); running stats EMA with

@@ -41,6 +41,7 @@ class WgradParams(Structure):
 SIGNATURES = {
     'ssdhip_version': (c_int, []),
     'ssdhip_last_error': (c_char_p, []),
+    'ssdhip_cu_count': (c_int, []),
     'ssdhip_default_boxes': (c_int, [c_void_p, POINTER(c_int32), c_int, c_double, c_double, c_void_p]),
     'ssdhip_normalize_nchw_to_nhwc4': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'ssdhip_pack_conv_weight': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -53,6 +54,11 @@ SIGNATURES = {
     'ssdhip_winograd_input': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'ssdhip_winograd_output': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'ssdhip_winograd_output_head': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'ssdhip_winograd4_tiles': (c_int, [c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    'ssdhip_winograd4_weight': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'ssdhip_winograd4_input': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'ssdhip_winograd4_stat_rows': (c_int, [c_int, c_int, c_int, c_int]),
+    'ssdhip_winograd4_output': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ssdhip_bn_finalize': (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'ssdhip_bn_fold_eval': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),

@@ -39,6 +39,11 @@ struct DeviceOnce {
     void mark(int dev) { if (dev >= 0 && dev < 64) __atomic_fetch_or(&mask, 1ull << dev, __ATOMIC_RELAXED); }
 };
 
+// Compute units of the current device (cached per device ordinal): the persistent grids and the split-K targets are derived from
+// it, so a partition with fewer CUs (CPX / DPX modes, other gfx9 parts) does not queue surplus persistent blocks behind full-length
+// ones.  256 on an MI355X in SPX mode; 256 if the query fails.
+extern "C" int ssdhip_cu_count(void);
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 __device__ __forceinline__ float wave_sum(float v) {

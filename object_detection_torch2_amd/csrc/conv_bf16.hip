@@ -442,7 +442,8 @@ int ssdhip_conv_bf16(const void* a, const void* wpk, const float* bias, void* z,
 #endif
     SSDHIP_REQUIRE(g.NB <= 256, "conv_bf16: too many channel tiles");
     const int64_t items = (int64_t)g.MB * g.NB;
-    const int cap = max_blocks > 0 && max_blocks < 256 ? (max_blocks < g.NB ? g.NB : max_blocks) : 256;
+    const int cus = ssdhip_cu_count();              // one persistent block per CU (128 KiB of LDS each)
+    const int cap = max_blocks > 0 && max_blocks < cus ? (max_blocks < g.NB ? g.NB : max_blocks) : cus;
     const int G = items < cap ? (int)items : cap / g.NB * g.NB;
     dim3 grid((unsigned)G), block(512);
     hipStream_t st = (hipStream_t)stream;

@@ -483,8 +483,9 @@ __global__ __launch_bounds__(1024) void conv_splitk_reduce_kernel(ConvArgs a, in
 static int plan_split(int MB, int NB, int KT, int64_t M, int Cout, int64_t ws_bytes, int& kt_per) {
     kt_per = KT;
     const int blocks = MB * NB;
-    if (blocks > 192 || KT < 8) return 1;
-    int ks = 384 / blocks;            // aim at ~1.5 blocks per CU
+    const int cus = ssdhip_cu_count();
+    if (blocks > cus * 3 / 4 || KT < 8) return 1;
+    int ks = cus * 3 / 2 / blocks;    // aim at ~1.5 blocks per CU
     if (ks > 8) ks = 8;
     if (ks > KT / 2) ks = KT / 2;
     while (ks > 1 && (int64_t)ks * M * Cout * 4 > ws_bytes) --ks;

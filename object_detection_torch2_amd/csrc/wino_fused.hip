@@ -892,7 +892,8 @@ int ssdhip_wino_fused_conv(const float* x, const float* upk, const float* bias, 
     // persistent grid: one block per CU, a multiple of NB so that a block keeps its channel tile (and its weight slice in L2)
     const int64_t items = (int64_t)a.MB * a.NB;
     // (max_blocks > 0 leaves CUs to kernels of other streams: a block fills its CU's LDS and registers for the whole launch)
-    const int cap = max_blocks > 0 && max_blocks < 256 ? (max_blocks < a.NB ? a.NB : max_blocks) : 256;
+    const int cus = ssdhip_cu_count();              // one persistent block fills a CU (160 KiB of LDS): never more blocks than CUs
+    const int cap = max_blocks > 0 && max_blocks < cus ? (max_blocks < a.NB ? a.NB : max_blocks) : cus;
     int G = items < cap ? (int)items : cap / a.NB * a.NB;
     dim3 grid((unsigned)G), block(256);
     hipStream_t st = (hipStream_t)stream;

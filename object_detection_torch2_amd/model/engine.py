@@ -50,6 +50,8 @@ class _ConvSpec:
         self.wino_head = is_head and k == 3 and stride == 1 and pad == 1 and cin >= 256
         self.wino_u = None
         self.wino_key = None
+        self.wino4_u = None      # F(4x4,3x3) weight planes (frozen backbone layers, forward only)
+        self.wino4_key = None
 
 
 class _Stage:
@@ -107,6 +109,17 @@ class Engine:
         # SSD_WF_BLOCKS unset: 224 of the 256 CUs while the backbone runs beside the tail's streams (the small dependent launches of the
         # tail then never queue behind a whole persistent launch: 12.35-12.46 vs 12.56-12.63 ms per step; 240 or 192 are worse), all
         # 256 when it runs alone
+        # A/B switches of DESIGN.md section 8, read once (a buffer set caches decisions taken from them)
+        self._no_splitk = os.environ.get('SSD_NO_SPLITK') == '1'
+        self._no_fused = os.environ.get('SSD_NO_FUSED_WINOGRAD') == '1'
+        self._no_patch = os.environ.get('SSD_NO_BF16_PATCH') == '1'
+        self._z_bf16 = os.environ.get('SSD_BF16_Z', 'bf16') == 'bf16'
+        # frozen 3x3 backbone layers on <= 80-px maps (conv_3_2 .. conv_5_3): Winograd F(4x4,3x3) (csrc/winograd4.hip: 1.78x fewer MFMA flops
+        # than F(2x2), 2.7x its rounding error, still 8x inside the per-layer bound of the tests); SSD_WINOGRAD=f2 keeps F(2x2) everywhere
+        self._wino_mode = os.environ.get('SSD_WINOGRAD', 'f4')
+        if self._wino_mode not in ('f2', 'f4'):
+            raise ValueError(f"SSD_WINOGRAD must be 'f2' or 'f4', got {self._wino_mode!r}")
+        self._cus = None       # compute units of the device (first forward): the persistent backbone grids take 7/8 of them beside the tail
         self._wf_blocks_env = os.environ.get('SSD_WF_BLOCKS')
         self._wf_blocks = int(self._wf_blocks_env) if self._wf_blocks_env is not None else 0
         self._fused_min = int(os.environ.get('SSD_FUSED_MIN', '70'))      # smallest map side that runs on the fused Winograd kernel
@@ -197,6 +210,10 @@ class Engine:
                 tiles = N * ((g['ho'] + 1) // 2) * ((g['wo'] + 1) // 2)
                 max_partial = max(max_partial, (max((M + 63) // 64, (tiles + 7) // 8, 4096 if s.conv.cin_pad == 4 else 0) + 8) * s.conv.cout * 2)
                 cmax = max(cmax, s.conv.cout)
+                if self._wino4_ok(s.conv, g, sizing=True):
+                    _, tp4, _ = self._wino4_plan(s.conv, g, N)
+                    wino_v, wino_m = max(wino_v, 36 * tp4 * s.conv.cin), max(wino_m, 36 * tp4 * s.conv.cout)
+                    max_partial = max(max_partial, (self.lib.ssdhip_winograd4_stat_rows(N, g['hi'], g['wi'], s.conv.cout) + 8) * s.conv.cout * 2)
                 if s.conv.wino and self._wino_ok(g):
                     tp = (N * ((g['hi'] + 1) // 2) * ((g['wi'] + 1) // 2) + 127) // 128 * 128
                     wino_v, wino_m = max(wino_v, 16 * tp * s.conv.cin), max(wino_m, 16 * tp * s.conv.cout)
@@ -224,7 +241,7 @@ class Engine:
     def _fused_ok(self, c, g, N):
         """Layers that run on the fused Winograd kernel: 3x3/s1/p1, wide maps (>= 70 px: from the 38x38 maps down the three-pass form
         is faster), channel counts the kernel tiles (Cin % 16, Cout % 64), tensors within its 32-bit offsets; fp32 mode only."""
-        if self.bf16 or c.is_head or os.environ.get('SSD_NO_FUSED_WINOGRAD') == '1':
+        if self.bf16 or c.is_head or self._no_fused:
             return False
         return (c.k == 3 and c.stride == 1 and c.pad == 1 and c.cin % 16 == 0 and 32 <= c.cin <= 512 and c.cout % 64 == 0
                 and min(g['hi'], g['wi']) >= self._fused_min and N * g['hi'] * g['wi'] * max(c.cin * 4, c.cout) < (1 << 31)
@@ -234,7 +251,7 @@ class Engine:
         """bf16 mode (BASELINE configs[3] / [4]): frozen 3x3/s1/p1 backbone layers run on the bf16 patch convolution (conv_bf16.hip),
         reading an ACTIVATED bf16 tensor with a zero halo that the producer's apply pass wrote -- the activations of the backbone are
         bf16 in HBM.  The trainable tail keeps the implicit-GEMM bf16 template (fp32 tensors, operands rounded at staging)."""
-        if not self.bf16 or i <= 0 or i >= len(self.stages) or i > self.tail_start or os.environ.get('SSD_NO_BF16_PATCH') == '1':
+        if not self.bf16 or i <= 0 or i >= len(self.stages) or i > self.tail_start or self._no_patch:
             return False
         c, g = self.stages[i].conv, geo[i]
         if i == self.tail_start and (self.stages[i - 1].pool_pad is not None or self.stages[i - 1].conv.is_head):
@@ -262,13 +279,13 @@ class Engine:
             spec.wino_key = key
         return spec.wino_u
 
-    def _plane_gemm(self, p, tp, cin, cout, w_plane_stride, what):
-        """ssdhip_conv2d_nhwc as 16 plane GEMMs; the kernel addresses its input with 32-bit byte offsets (2^30 elements), so big batches
-        run the planes in 2, 4 or 8 groups (same kernel, pointers advanced)."""
+    def _plane_gemm(self, p, tp, cin, cout, w_plane_stride, what, planes=16):
+        """ssdhip_conv2d_nhwc as 16 (F(2x2)) or 36 (F(4x4)) plane GEMMs; the kernel addresses its input with 32-bit byte offsets (2^30
+        elements), so big batches run the planes in groups (same kernel, pointers advanced)."""
         groups = 1
-        while (16 // groups) * tp * max(cin, cout) >= self._plane_limit and groups < 16:
-            groups *= 2
-        per = 16 // groups
+        while (planes // groups) * tp * max(cin, cout) >= self._plane_limit and groups < planes:
+            groups = next(d for d in range(groups + 1, planes + 1) if planes % d == 0)
+        per = planes // groups
         x0, w0, y0 = p.x, p.w, p.y
         p.N = per
         for gi in range(groups):
@@ -276,7 +293,66 @@ class Engine:
             p.w = w0 + gi * per * w_plane_stride * 4
             p.y = y0 + gi * per * tp * cout * 4
             _lib.check(self.lib.ssdhip_conv2d_nhwc(ctypes.byref(p), _lib.stream()), what)
-        p.x, p.w, p.y, p.N = x0, w0, y0, 16
+        p.x, p.w, p.y, p.N = x0, w0, y0, planes
+
+    def _wino4_ok(self, c, g, sizing=False):
+        """Layers on the Winograd F(4x4,3x3) passes: frozen (forward only: no gradient is computed from or through them), 3x3/s1/p1,
+        K = Cin >= 256 (the transforms move 2.25x the activation bytes each way: they pay for themselves from K = 256 on), maps of
+        8 .. 80 px (conv_3_2 .. conv_5_3 of SSD300: 75, 38, 19 px; 64 and 32 px of SSD512); fp32 mode only."""
+        return (self._wino_mode == 'f4' and (sizing or not self.bf16) and c.frozen and not c.is_head and c.k == 3 and c.stride == 1 and c.pad == 1
+                and c.cin >= 256 and c.cin % 32 == 0 and c.cout % 4 == 0 and 256 % (c.cout // 4) == 0
+                and 8 <= min(g['hi'], g['wi']) and max(g['hi'], g['wi']) <= 80)
+
+    def _wino4_plan(self, c, g, N):
+        """(tiles, padded tiles per plane, GEMM tile code) of an F(4x4) layer: 128x128 GEMM tiles once the grid has > 2000 of them, else
+        64x128 (and planes padded to 64 rows only: 800 tiles of a 19x19 map at batch 32 -> 832, not 896)."""
+        T = N * ((g['hi'] + 3) // 4) * ((g['wi'] + 3) // 4)
+        tp128 = _rup(T, 128)
+        if (36 * tp128 // 128) * ((c.cout + 127) // 128) > 2000:
+            return T, tp128, 128128
+        return T, _rup(T, 64), 64128
+
+    def _wino4_weights(self, spec):
+        w, _ = self._weight(spec)
+        key = (w.data_ptr(), w._version, self.m._hip_epoch if not spec.frozen else 0)
+        if spec.wino4_u is None or spec.wino4_u.device != w.device:
+            spec.wino4_u = torch.empty(36 * spec.rows_pad * spec.cin, device=w.device, dtype=torch.float32)
+            spec.wino4_key = None
+        if spec.wino4_key != key:
+            _lib.check(self.lib.ssdhip_winograd4_weight(_lib.ptr(w), _lib.ptr(spec.wino4_u), spec.cout, spec.cin, spec.rows_pad, spec.cin,
+                                                        _lib.stream()), 'winograd4_weight')
+            spec.wino4_key = key
+        return spec.wino4_u
+
+    def _conv_winograd4(self, spec, x, xs, z, ws, N, h, w, g, stats):
+        """3x3/s1/p1 conv as F(4x4,3x3): input transform -> 36 plane GEMMs (one launch) -> output transform.  Returns the number of BN
+        partial rows written to `stats`."""
+        L, st = self.lib, _lib.stream()
+        U = self._wino4_weights(spec)
+        _, bias = self._weight(spec)
+        V, Mo = ws['wino_v'], ws['wino_m']
+        T, tp, tile = self._wino4_plan(spec, g, N)
+        _lib.check(L.ssdhip_winograd4_input(_lib.ptr(x), _lib.ptr(xs[0]) if xs is not None else None,
+                                            _lib.ptr(xs[1]) if xs is not None else None, _lib.ptr(V), N, h, w, spec.cin, tp, st), f'winograd4_input {spec.name}')
+        p = _lib.ConvParams()
+        p.x, p.w, p.y, p.y_batch_stride = V.data_ptr(), U.data_ptr(), Mo.data_ptr(), tp * spec.cout
+        p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout = 36, 1, tp, spec.cin, 1, tp, spec.cout
+        p.R, p.S, p.stride, p.pad, p.KP, p.mode, p.accumulate = 1, 1, 1, 0, spec.cin, 0, 0
+        p.tile = tile
+        p.rows_per_img, p.w_img_stride = tp, spec.rows_pad * spec.cin
+        if self.prof is None:
+            self._plane_gemm(p, tp, spec.cin, spec.cout, spec.rows_pad * spec.cin, f'winograd4 gemm {spec.name}', planes=36)
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._plane_gemm(p, tp, spec.cin, spec.cout, spec.rows_pad * spec.cin, f'winograd4 gemm {spec.name}', planes=36)
+            e1.record()
+            self.prof.append(dict(layer=spec.name + ' (F(4x4) winograd-domain GEMM)',
+                                  kernel='gemm_planes_dma_kernel<%d, 128, 0, 8, 0>' % (tile // 1000),
+                                  direct_flops=2.0 * N * h * w * spec.cin * spec.cout * 9,
+                                  flops=2.0 * 36 * tp * spec.cin * spec.cout, e0=e0, e1=e1))
+        return _lib.check(L.ssdhip_winograd4_output(_lib.ptr(Mo), _lib.ptr(bias), _lib.ptr(z), _lib.ptr(stats), N, h, w, spec.cout, tp, st),
+                          f'winograd4_output {spec.name}')
 
     def _conv_winograd(self, spec, x, xs, z, ws, N, h, w, stats):
         """3x3/s1/p1 conv as input transform -> 16 plane GEMMs (one launch of the implicit-GEMM kernel) -> output transform.
@@ -373,16 +449,21 @@ class Engine:
     def _splitk_ws(self, spec, p, tag):
         """Split-K workspace of one (layer, direction): launches on the tiny maps split K over blocks (conv_igemm.hip).  One buffer
         per layer and direction, because heads, tail convolutions and data gradients of different layers run on different streams."""
-        if os.environ.get('SSD_NO_SPLITK') == '1':
+        if self._no_splitk:
             return
         need = self.lib.ssdhip_conv2d_ws_bytes(ctypes.byref(p))
         if need <= 0:
             return
+        # keyed by direction only and grown to the largest need: ragged last batches, evaluation and inference batch sizes must not
+        # each leave their own slab set behind (launches of one layer and direction are ordered on one stream, whatever the batch)
         bufs = spec.__dict__.setdefault('splitk_ws', {})
-        buf = bufs.get(tag)
+        key = tag[0]
+        buf = bufs.get(key)
         if buf is None or buf.numel() * 4 < need or buf.device.index != torch.cuda.current_device():
+            if buf is not None and buf.device.index == torch.cuda.current_device():
+                buf.record_stream(torch.cuda.current_stream())      # its last reader is on this stream: recycle only behind it
             buf = torch.empty((need + 3) // 4, device=torch.device('cuda', torch.cuda.current_device()), dtype=torch.float32)
-            bufs[tag] = buf
+            bufs[key] = buf
         p.ws, p.ws_bytes = buf.data_ptr(), buf.numel() * 4
 
     # ------------------------------------------------------------------------------------------------ streams
@@ -452,8 +533,11 @@ class Engine:
         # launches that cannot fill the chip).  Only two backbone outputs have consumers outside the backbone stream -- the inputs
         # of det_4_3 and of conv_6_1 (forward and weight gradient): those stages wait for the events their readers leave in _readers.
         bb = None if (self.single_stream or self.tail_start == 0) else self._side_stream(dev, which=2)
+        if self._cus is None:
+            self._cus = int(self.lib.ssdhip_cu_count())
         if self._wf_blocks_env is None:
-            self._wf_blocks = 224 if (bb is not None and self.tail_start < len(self.stages)) else 0
+            # 7/8 of the CUs (224 of 256 on an MI355X), a multiple of 32 so that every XCD gets whole channel-tile groups
+            self._wf_blocks = max(32, self._cus * 7 // 8 // 32 * 32) if (bb is not None and self.tail_start < len(self.stages)) else 0
         entry = main.record_event() if fork.side_stream is not None else None
         if fork.side_stream is not None:
             fork.side_stream.wait_event(entry)               # `out` may reuse memory that step i's loss kernels still read
@@ -506,7 +590,7 @@ class Engine:
                 patch, nxt_patch = pk[(i, self.bf16)], pk[(i + 1, self.bf16)]
                 # z of a patch layer is bf16 when only the next layer's apply pass reads it (no head, no fp32 consumer)
                 z_bf16 = (patch and nxt_patch and s.head is None and i + 1 < self.tail_start
-                          and os.environ.get('SSD_BF16_Z', 'bf16') == 'bf16')
+                          and self._z_bf16)
                 if patch:
                     w1, b1 = self._weight(c)
                     key = (w1.data_ptr(), w1._version, self.m._hip_epoch if not c.frozen else 0)
@@ -527,6 +611,8 @@ class Engine:
                         fl = 2.0 * N * g['hi'] * g['wi'] * c.cin * c.cout * 9
                         self.prof.append(dict(layer=c.name + ' (bf16 patch)', e0=e0, e1=e1, flops=fl, peak_tflops=2500.0,
                                               kernel='conv_bf16_kernel<%s, %s>' % ('4, 2, 2' if c.cout % 128 == 0 else '2, 2, 1', 'true' if z_bf16 else 'false')))
+                elif self._wino4_ok(c, g):
+                    rows = self._conv_winograd4(c, cur, cur_xs, z, ws, N, g['hi'], g['wi'], g, ws['partial'] if training else None)
                 elif self._fused_ok(c, g, N):
                     # conv_1_2 .. conv_3_3 (300x300 .. 75x75 maps): the one-kernel Winograd form (wino_fused.hip); nothing of the
                     # Winograd domain in HBM.  Measured against the paths below (scripts/wf_bench.py, batch 32): conv_1_2 1.57 vs 1.80 ms,

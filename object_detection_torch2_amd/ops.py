@@ -346,3 +346,50 @@ def conv3x3_winograd(x, w_oihw, bias=None, in_scale=None, in_shift=None, want_st
     stats = torch.empty((T + 7) // 8, cout, 2, device=dev, dtype=torch.float32) if want_stats else None
     _lib.check(lib.ssdhip_winograd_output(_lib.ptr(Mo), _lib.ptr(bias), _lib.ptr(z), _lib.ptr(stats), N, H, W, cout, st), 'winograd_output')
     return z, stats
+
+
+# Winograd F(4x4,3x3) matrices for the points (0, 3/2, -3/2, 2/3, -2/3, inf) as exact rationals (csrc/winograd4.hip holds the same
+# numbers as float / double constants; tests/test_host_cpu.py checks the convolution identity in exact arithmetic)
+WINOGRAD4_BT = [['1', '0', '-97/36', '0', '1', '0'], ['0', '-2/3', '-4/9', '3/2', '1', '0'], ['0', '2/3', '-4/9', '-3/2', '1', '0'],
+                ['0', '-3/2', '-9/4', '2/3', '1', '0'], ['0', '3/2', '-9/4', '-2/3', '1', '0'], ['0', '1', '0', '-97/36', '0', '1']]
+WINOGRAD4_G = [['1', '0', '0'], ['8/65', '12/65', '18/65'], ['8/65', '-12/65', '18/65'], ['-81/130', '-27/65', '-18/65'],
+               ['-81/130', '27/65', '-18/65'], ['0', '0', '1']]
+WINOGRAD4_AT = [['1', '1', '1', '1', '1', '0'], ['0', '3/2', '-3/2', '2/3', '-2/3', '0'], ['0', '9/4', '9/4', '4/9', '4/9', '0'],
+                ['0', '27/8', '-27/8', '8/27', '-8/27', '1']]
+
+
+def conv3x3_winograd4(x, w_oihw, bias=None, in_scale=None, in_shift=None, want_stats=False, tile=0):
+    """3x3 / stride 1 / pad 1 convolution through the Winograd F(4x4,3x3) passes (csrc/winograd4.hip).  x (N,H,W,Cin) NHWC,
+    Cin % 32 == 0.  Returns (z (N,H,W,Cout), stats (rows,Cout,2) or None)."""
+    _lib.require_gpu(x, w_oihw)
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    cout, cin, k, _ = w_oihw.shape
+    if k != 3 or cin != C or C % 32:
+        raise ValueError('conv3x3_winograd4: 3x3 kernels, Cin % 32 == 0')
+    row_pad = 64 if tile and tile // 1000 == 64 else 128
+    T, Tp = ctypes.c_int(), ctypes.c_int()
+    _lib.check(lib.ssdhip_winograd4_tiles(N, H, W, row_pad, ctypes.byref(T), ctypes.byref(Tp)), 'winograd4_tiles')
+    T, Tp = T.value, Tp.value
+    rows_pad = _rup(cout, 128)
+    dev = x.device
+    U = torch.empty(36 * rows_pad * C, device=dev, dtype=torch.float32)
+    V = torch.empty(36 * Tp * C, device=dev, dtype=torch.float32)
+    Mo = torch.empty(36 * Tp * cout, device=dev, dtype=torch.float32)
+    z = torch.empty(N, H, W, cout, device=dev, dtype=torch.float32)
+    st = _lib.stream()
+    _lib.check(lib.ssdhip_winograd4_weight(_lib.ptr(_lib.f32c(w_oihw)), _lib.ptr(U), cout, cin, rows_pad, C, st), 'winograd4_weight')
+    if Tp > T:
+        V.view(36, Tp, C)[:, T:].zero_()          # padding rows of every plane feed the GEMM (their products are never read back)
+    _lib.check(lib.ssdhip_winograd4_input(_lib.ptr(x), _lib.ptr(in_scale), _lib.ptr(in_shift), _lib.ptr(V), N, H, W, C, Tp, st), 'winograd4_input')
+    p = _lib.ConvParams()
+    p.x, p.w, p.y, p.y_batch_stride = V.data_ptr(), U.data_ptr(), Mo.data_ptr(), Tp * cout
+    p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout = 36, 1, Tp, C, 1, Tp, cout
+    p.R, p.S, p.stride, p.pad, p.KP, p.mode, p.accumulate, p.tile = 1, 1, 1, 0, C, 0, 0, tile or 128128
+    p.rows_per_img, p.w_img_stride = Tp, rows_pad * C
+    _lib.check(lib.ssdhip_conv2d_nhwc(ctypes.byref(p), st), 'winograd4 gemm')
+    rows = _lib.check(lib.ssdhip_winograd4_stat_rows(N, H, W, cout), 'winograd4_stat_rows')
+    stats = torch.empty(rows, cout, 2, device=dev, dtype=torch.float32) if want_stats else None
+    got = _lib.check(lib.ssdhip_winograd4_output(_lib.ptr(Mo), _lib.ptr(bias), _lib.ptr(z), _lib.ptr(stats), N, H, W, cout, Tp, st), 'winograd4_output')
+    assert got == rows
+    return z, stats

@@ -117,7 +117,7 @@ def test_model_bf16_forward_and_training_close_to_fp32(golden):
     fx = golden('g8_forward.npz')
     assert np.abs(y32.cpu().numpy()[:, ::7] - fx['fwd_train_rows']).max() < 2e-3
     # bf16 operands cost 2^-9 per product; the random-init network amplifies input noise ~16x over its 20+ train-mode-BN layers
-    # (the same factor takes fp32's 6e-8 to the 1e-6 seen against fp64), most of it in the tiny late maps (scripts/bf16_check.py:
+    # (the same factor takes fp32's 6e-8 to the 1e-6 seen against fp64), most of it in the tiny late maps (tests/tools/bf16_check.py:
     # relative L2 error 3 % on the 38x38 head, 6.5 % over all priors)
     d = (y16 - y32).cpu().numpy()
     ref = y32.cpu().numpy()

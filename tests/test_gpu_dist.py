@@ -31,11 +31,11 @@ def test_two_rank_classification_step_on_one_gpu():
 
 
 def test_two_rank_pipelined_steps_match_serialised_streams():
-    """Several data-parallel steps without host synchronisation, backbone overlap enabled (scripts/dp_probe.py): bit-identical to the
+    """Several data-parallel steps without host synchronisation, backbone overlap enabled (tests/tools/dp_probe.py): bit-identical to the
     same run with the streams serialised, and identical weights on both ranks."""
     env = dict(os.environ, SSD_DIST_BACKEND='gloo', SSD_FORCE_DEVICE='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29535', os.path.join(ROOT, 'scripts', 'dp_probe.py')]
+           '--master-port', '29535', os.path.join(ROOT, 'tests', 'tools', 'dp_probe.py')]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count('pipelined == serialised: True; ranks identical: True') == 2

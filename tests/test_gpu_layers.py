@@ -278,6 +278,44 @@ def test_conv3x3_winograd(case):
     assert rel_err(z2.permute(0, 3, 1, 2).cpu(), ref2) < 1e-4
 
 
+# (N, H, W, Cin, Cout, GEMM tile): maps that are / are not multiples of the 4x4 output tile, both GEMM tile sizes (planes padded to 128 / 64 rows)
+WINO4_CASES = [(2, 19, 19, 256, 256, 0), (1, 38, 38, 256, 512, 0), (3, 10, 13, 512, 256, 64128), (1, 75, 75, 256, 256, 0), (2, 16, 16, 512, 1024, 64128),
+               (1, 8, 8, 256, 64, 0)]
+
+
+@pytest.mark.parametrize('case', WINO4_CASES)
+def test_conv3x3_winograd4(case):
+    """Winograd F(4x4,3x3) passes (csrc/winograd4.hip, points 0, +-3/2, +-2/3) vs F.conv2d, incl. the fused BN+ReLU input transform (zero
+    padding after it), bias and the BatchNorm partial sums.  Same 1e-4 bound against torch's fp32 convolution as the other Winograd
+    kernels; against an fp64 convolution the F(4x4) error stays below 1e-5 of the output scale (measured 2-4e-6; F(2x2): 5e-7)."""
+    from object_detection_torch2_amd import ops
+    N, H, W, cin, cout, tile = case
+    zprev = rnd(N, cin, H, W, seed=231)
+    scale, shift = rnd(cin, seed=232), rnd(cin, seed=233) + 0.5
+    w = rnd(cout, cin, 3, 3, seed=234, scale=(2.0 / (cin * 9)) ** 0.5)
+    b = rnd(cout, seed=235)
+    a = F.relu(zprev * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    ref = F.conv2d(a, w, b, padding=1)
+    ref64 = F.conv2d(a.double(), w.double(), b.double(), padding=1)
+    x = ops.to_nhwc(zprev.to(DEV))
+    z, stats = ops.conv3x3_winograd4(x, w.to(DEV), b.to(DEV), in_scale=scale.to(DEV), in_shift=shift.to(DEV), want_stats=True, tile=tile)
+    got = z.permute(0, 3, 1, 2).cpu()
+    assert rel_err(got, ref) < 1e-4
+    e4 = rel_err(got.double(), ref64)
+    assert e4 < 1e-5, e4
+    s = stats.sum(dim=0).cpu()
+    assert torch.allclose(s[:, 0], ref.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(s[:, 1], (ref * ref).sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
+    # plain input (layer after a pool), no bias
+    ref2 = F.conv2d(zprev, w, None, padding=1)
+    z2, _ = ops.conv3x3_winograd4(x, w.to(DEV), tile=tile)
+    assert rel_err(z2.permute(0, 3, 1, 2).cpu(), ref2) < 1e-4
+    # against the F(2x2) kernels on the same operands: two roundings of the same convolution
+    z3, _ = ops.conv3x3_winograd(x, w.to(DEV), b.to(DEV), in_scale=scale.to(DEV), in_shift=shift.to(DEV))
+    assert rel_err(z.cpu(), z3.cpu()) < 1e-5
+    print(f'winograd4 {case}: max err / max |out| vs fp64 {e4:.2e}; F(2x2) {rel_err(z3.permute(0, 3, 1, 2).cpu().double(), ref64):.2e}; torch fp32 {rel_err(ref.double(), ref64):.2e}')
+
+
 # (N, H, W, Cin, Cout): odd / even maps, ragged last tile block (T % 64 != 0), one and several channel tiles, short and long K
 WINO_FUSED_CASES = [(2, 19, 19, 64, 64), (1, 38, 38, 64, 128), (3, 9, 11, 32, 64), (2, 30, 30, 128, 256), (1, 16, 12, 512, 192),
                     (5, 11, 13, 48, 64), (1, 150, 150, 32, 64)]

@@ -80,7 +80,7 @@ def test_gradients_vs_oracle_autograd(env):
         if 'features.conv' in k and k.endswith('.bias'):
             continue    # analytically zero (BN cancels the conv bias): both sides hold rounding noise only
         # A ReLU whose pre-activation is within fp32 rounding of 0 may switch between two fp32 implementations
-        # (scripts/act_check.py: 0-13 of ~1e6 elements per layer, for torch-fp32 vs fp64 as well); one switched unit
+        # (tests/tools/act_check.py: 0-13 of ~1e6 elements per layer, for torch-fp32 vs fp64 as well); one switched unit
         # moves individual weight gradients by percents, so the layer gradients are compared in L2 / direction and
         # the per-kernel tests (test_gpu_layers.py) carry the tight element-wise bound.
         rel = ((g - r).norm() / r.norm()).item()
@@ -152,7 +152,7 @@ def test_train_trajectory_vs_golden(env, golden):
     # near 3e-3 would hold for ANY Adam; these bounds are 10x below that.  Adam divides by sqrt(v): an element whose gradient is
     # of the size of its fp32 rounding error can take a step of opposite sign, which only happens in the conv weights behind ReLU
     # units at rounding distance of 0 (test_gradients_no_worse_than_torch_fp32): for those the bulk is bounded, not the tail.
-    # Measured (scripts/tol_probe.py): det_4_3.weight 1.9e-5, bn_7_1.weight 2.8e-5, det_11_2.bias 3.0e-5, bn_11_2.bias 8.3e-5;
+    # Measured (tests/tools/tol_probe.py): det_4_3.weight 1.9e-5, bn_7_1.weight 2.8e-5, det_11_2.bias 3.0e-5, bn_11_2.bias 8.3e-5;
     # conv weights median 5e-5 / 8.5e-5.  The reference-vs-oracle difference on the same tensors is 5e-6 .. 9e-6.
     sd = net.state_dict()
     init = O.init_state(seed=1)

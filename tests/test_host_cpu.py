@@ -210,3 +210,37 @@ def test_product_library_refuses_probe_tile_codes():
         p.tile = code
         assert lib.ssdhip_conv2d_nhwc(ctypes.byref(p), None) == _lib.EINVAL
         assert b'tile' in lib.ssdhip_last_error()
+
+
+
+def test_winograd4_matrices_are_exact():
+    """The F(4x4,3x3) matrices of csrc/winograd4.hip (copies in ops.WINOGRAD4_*) satisfy the correlation identity in exact rational
+    arithmetic: y_i = sum_k g_k d_{i+k} == sum_p AT[i][p] (G g)[p] (BT d)[p] for every monomial, i.e. sum_p AT[i][p] G[p][k] BT[p][j] =
+    [j == i + k]; and the float constants in the kernel source are these rationals."""
+    import os
+    import re
+    from fractions import Fraction as Fr
+    from object_detection_torch2_amd import ops
+    BT = [[Fr(v) for v in r] for r in ops.WINOGRAD4_BT]
+    G = [[Fr(v) for v in r] for r in ops.WINOGRAD4_G]
+    AT = [[Fr(v) for v in r] for r in ops.WINOGRAD4_AT]
+    assert (len(BT), len(BT[0]), len(G), len(G[0]), len(AT), len(AT[0])) == (6, 6, 6, 3, 4, 6)
+    for i in range(4):
+        for k in range(3):
+            for j in range(6):
+                assert sum(AT[i][p] * G[p][k] * BT[p][j] for p in range(6)) == (1 if j == i + k else 0), (i, k, j)
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'object_detection_torch2_amd', 'csrc', 'winograd4.hip')).read()
+    consts = dict(re.findall(r'(kC\w+) = ([0-9.f /]+?)[,;]', src))
+    want = {'kC97_36': Fr(97, 36), 'kC4_9': Fr(4, 9), 'kC9_4': Fr(9, 4), 'kC3_2': Fr(3, 2), 'kC2_3': Fr(2, 3), 'kC27_8': Fr(27, 8), 'kC8_27': Fr(8, 27)}
+    assert set(consts) == set(want), consts
+    for name, expr in consts.items():
+        parts = [Fr(t.strip().rstrip('f')) for t in expr.split('/')]
+        val = parts[0] / parts[1] if len(parts) == 2 else parts[0]
+        assert val == want[name], (name, expr)
+    used = {abs(v) for r in BT + AT for v in r} - {Fr(0), Fr(1)}
+    assert used == set(want.values())
+    for row in re.findall(r'\{(-?[0-9.]+ / [0-9.]+|[-0-9.]+), (-?[0-9.]+ / [0-9.]+|[-0-9.]+), (-?[0-9.]+ / [0-9.]+|[-0-9.]+)\}', src):
+        pass
+    grows = re.search(r'const double G\[6\]\[3\] = \{(.*?)\};', src, re.S).group(1)
+    vals = [Fr(a.replace('.0', '')) / Fr(b.replace('.0', '')) if b else Fr(a.replace('.0', '')) for a, b in re.findall(r'(-?[0-9.]+)(?: / ([0-9.]+))?', grows)]
+    assert vals == [v for r in G for v in r]

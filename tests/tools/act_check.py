@@ -1,6 +1,6 @@
 """Per-stage activation error of the HIP forward and of torch fp32, both vs an fp64 forward; ReLU mask flips."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, torch.nn.functional as F
 from oracle import ssd_oracle as O
 from object_detection_torch2_amd import synth

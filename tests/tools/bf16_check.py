@@ -1,6 +1,6 @@
 """bf16 compute mode vs fp32 mode on the same weights/batch: output error statistics per detector head."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import ssd_oracle as O
 from object_detection_torch2_amd import synth

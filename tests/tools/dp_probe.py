@@ -1,8 +1,8 @@
 """Data-parallel + stream pipelining rehearsal on ONE GPU (2 ranks over gloo): several steps without host synchronisation, with the
 backbone overlap enabled; the run must be bit-identical to the same run with SSD_SINGLE_STREAM semantics and across ranks.
-Launch: SSD_DIST_BACKEND=gloo SSD_FORCE_DEVICE=0 python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 scripts/dp_probe.py"""
+Launch: SSD_DIST_BACKEND=gloo SSD_FORCE_DEVICE=0 python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tests/tools/dp_probe.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, torch.distributed as dist
 from oracle import ssd_oracle as O
 from object_detection_torch2_amd import parallel, synth

@@ -1,7 +1,7 @@
 """One-off evidence at the headline batch: the full forward, loss and tail gradients at N = 32 against the CPU oracle (torch CPU ops
 + numpy loss restatement).  Takes a few minutes of host time, so it is a script, not a test."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import ssd_oracle as O
 from object_detection_torch2_amd import synth

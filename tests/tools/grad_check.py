@@ -1,6 +1,6 @@
 """Conditioning check: HIP gradients and torch-fp32 gradients, both against an fp64 run of the oracle."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import ssd_oracle as O
 from object_detection_torch2_amd import synth

@@ -1,7 +1,7 @@
 """Stress for cross-stream ordering: many train steps without host synchronisation, several fresh modules in one process;
 reports non-finite state and mismatches against the single-stream run (bit-identical results are expected)."""
 import sys, os, gc
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import ssd_oracle as O
 from object_detection_torch2_amd import synth

@@ -2,7 +2,7 @@
 fixture, per tensor; (b) per-tensor gradient error of the HIP path and of torch fp32, both against an fp64 run of the oracle, with
 one common dL/d outputs."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import ssd_oracle as O
 from object_detection_torch2_amd import synth
@@ -10,7 +10,7 @@ from object_detection_torch2_amd.model import SSD
 from object_detection_torch2_amd.optim import FusedAdam
 torch.set_num_threads(16)
 DEV = 'cuda:0'
-fx = np.load(os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden', 'g9_train.npz'))
+fx = np.load(os.path.join(os.path.dirname(__file__), '..', 'golden', 'g9_train.npz'))
 net = SSD(21); net.load_state_dict(O.init_state(1)); net.to(DEV)
 init = {k: v.clone() for k, v in O.init_state(1).items()}
 opt = FusedAdam(net.train_params(), lr=1e-3, weight_decay=5e-4)
