@@ -612,10 +612,12 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
     a.ksplit = 1; a.kt_per = a.KT; a.slab = p->ws;
     if (p->rows_per_img > 0 && !p->bias && !p->stats && !p->accumulate && p->R == 1 && !p->in_scale && a.M % BM == 0 &&
         p->y_batch_stride == (int64_t)p->Ho * p->Wo * p->Cout) {
-        // short-K plane GEMMs: amortise pipeline fill/drain over several m-tiles, but keep >= ~6 blocks per CU
+        // short-K plane GEMMs: amortise pipeline fill/drain over several m-tiles, but keep >= ~6 blocks per CU.  Two tiles per block
+        // measured worse than one AND than three on every shape (3,600-tile GEMMs of the 36-plane F(4x4) layers: 537 vs 505 / 507 us on
+        // conv_4_2, 287 vs 277 / 276 on conv_4_1; scripts/w4_bench.py with tile codes 40..49 of the probe build), so 2 becomes 1
         const int64_t tiles = (int64_t)a.MB * a.NB;
         a.tpb = (int)(tiles / (256 * 6));
-        if (a.tpb < 1) a.tpb = 1;
+        if (a.tpb < 1 || a.tpb == 2) a.tpb = 1;
         if (a.tpb > 8) a.tpb = 8;
         // plain row-major planes: stage with the LDS-DMA engine (gemm_planes.hip) unless tile code 9xxxxxx asks for the
         // register-staged kernel (A/B comparison in scripts/wino_bench.py)

@@ -31,6 +31,7 @@
 //         [ 0    1      0  -97/36   0  1 ]         [   0        0       1    ]
 // The +- point pairs make rows 1/2 and 3/4 an even part +- an odd part: 14 operations per 6-vector instead of 36.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -53,45 +54,84 @@ __device__ __forceinline__ void bt6(float4& d0, float4& d1, float4& d2, float4& 
     const float4 v5 = f4fma(-kC97_36, d3, f4add(d1, d5));
     d0 = v0; d1 = f4add(e1, o1); d2 = f4sub(e1, o1); d3 = f4add(e2, o2); d4 = f4sub(e2, o2); d5 = v5;
 }
+__device__ __forceinline__ void bt6(float2& d0, float2& d1, float2& d2, float2& d3, float2& d4, float2& d5) {
+#define SSD_BT6(c)                                                                                              \
+    {                                                                                                           \
+        const float v0 = fmaf(-kC97_36, d2.c, d0.c + d4.c);                                                     \
+        const float e1 = fmaf(-kC4_9, d2.c, d4.c), o1 = fmaf(-kC2_3, d1.c, kC3_2 * d3.c);                       \
+        const float e2 = fmaf(-kC9_4, d2.c, d4.c), o2 = fmaf(-kC3_2, d1.c, kC2_3 * d3.c);                       \
+        const float v5 = fmaf(-kC97_36, d3.c, d1.c + d5.c);                                                     \
+        d0.c = v0; d1.c = e1 + o1; d2.c = e1 - o1; d3.c = e2 + o2; d4.c = e2 - o2; d5.c = v5;                   \
+    }
+    SSD_BT6(x) SSD_BT6(y)
+#undef SSD_BT6
+}
+__device__ __forceinline__ float4 act4(float4 v, float4 sc, float4 sh) {
+    return make_float4(fmaxf(fmaf(v.x, sc.x, sh.x), 0.f), fmaxf(fmaf(v.y, sc.y, sh.y), 0.f), fmaxf(fmaf(v.z, sc.z, sh.z), 0.f),
+                       fmaxf(fmaf(v.w, sc.w, sh.w), 0.f));
+}
+__device__ __forceinline__ float2 act4(float2 v, float2 sc, float2 sh) {
+    return make_float2(fmaxf(fmaf(v.x, sc.x, sh.x), 0.f), fmaxf(fmaf(v.y, sc.y, sh.y), 0.f));
+}
+template <typename VT> __device__ __forceinline__ VT vzero();
+template <> __device__ __forceinline__ float4 vzero<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+template <> __device__ __forceinline__ float2 vzero<float2>() { return make_float2(0.f, 0.f); }
 
-// one thread = one tile x 4 channels
-template <bool XFORM>
-__global__ __launch_bounds__(256) void winograd4_input_kernel(const float4* __restrict__ x, const float4* __restrict__ scale,
-                                                              const float4* __restrict__ shift, float4* __restrict__ V, int H, int W,
-                                                              int C4, int TH, int TW, int T, int Tp) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)T * C4) return;
-    const int c4 = (int)(idx % C4);
-    const int t = (int)(idx / C4);
+// one thread = one tile x 4 (VT = float4) or 2 (float2) channels; CV = C / channels per thread.  The float2 form needs ~100 registers
+// instead of ~175 (36 patch values live at once), i.e. 4-5 waves per SIMD instead of 2: with the producer's BN.ReLU fused the float4 form
+// ran at 3.3-3.5 TB/s on the 38 / 75 px maps, the form without it (168 registers, 3 waves) at 5.3 TB/s.
+template <bool XFORM, typename VT>
+__global__ __launch_bounds__(256) void winograd4_input_kernel(const VT* __restrict__ x, const VT* __restrict__ scale,
+                                                              const VT* __restrict__ shift, VT* __restrict__ V, int H, int W,
+                                                              int CV, int TH, int TW, int T, int Tp) {
+    // consecutive blocks land on different XCDs (round-robin), each with its own L2, while neighbouring tiles share a third of their
+    // 6x6 patches: give every XCD a contiguous eighth of the tiles, so that the 2.25x patch overlap is served by ONE L2 instead of being
+    // fetched through the fabric by each of them (conv_4_2: 3.7 -> see scripts/w4_bench.py)
+    int bid;
+    {
+        const int nb = gridDim.x, xcd = blockIdx.x & 7, local = blockIdx.x >> 3, q = nb >> 3, r = nb & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int64_t idx = (int64_t)bid * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)T * CV) return;
+    const int cv = (int)(idx % CV);
+    const int t = (int)(idx / CV);
     const int tw = t % TW;
     const int q = t / TW;
     const int th = q % TH;
     const int n = q / TH;
-    float4 sc, sh;
-    if (XFORM) { sc = scale[c4]; sh = shift[c4]; }
-    float4 d[6][6];
+    VT sc, sh;
+    if (XFORM) { sc = scale[cv]; sh = shift[cv]; }
+    // all 36 loads are issued unconditionally (addresses clamped into the image) and back to back; activation and the zero padding
+    // AFTER it are applied to the registers afterwards.  (Loads inside `if (inside)` blocks were compiled as 36 exec-masked
+    // load / wait / activate sequences: one memory latency each, 3.5 TB/s.)
+    VT d[6][6];
+    const VT* xn = x + (size_t)n * H * W * CV + cv;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        const int h = 4 * th - 1 + i;
+        const int h = min(max(4 * th - 1 + i, 0), H - 1);
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            const int w = 4 * tw - 1 + j;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
-                v = x[((size_t)(n * H + h) * W + w) * C4 + c4];
-                if (XFORM) {
-                    v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-                    v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
-                }
-            }
-            d[i][j] = v;
+            const int w = min(max(4 * tw - 1 + j, 0), W - 1);
+            d[i][j] = xn[(size_t)(h * W + w) * CV];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const bool hin = (unsigned)(4 * th - 1 + i) < (unsigned)H;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const bool in = hin && (unsigned)(4 * tw - 1 + j) < (unsigned)W;
+            VT v = d[i][j];
+            if (XFORM) v = act4(v, sc, sh);
+            d[i][j] = in ? v : vzero<VT>();
         }
     }
     // d B: every patch row as a 6-vector; then B^T (.) on every column
 #pragma unroll
     for (int i = 0; i < 6; ++i) bt6(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);
-    const size_t plane = (size_t)Tp * C4;
-    float4* o = V + (size_t)t * C4 + c4;
+    const size_t plane = (size_t)Tp * CV;
+    VT* o = V + (size_t)t * CV + cv;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         bt6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);
@@ -240,17 +280,32 @@ int ssdhip_winograd4_input(const float* x, const float* in_scale, const float* i
     int T, Tp128;
     SSDHIP_REQUIRE(ssdhip_winograd4_tiles(N, H, W, 128, &T, &Tp128) == SSDHIP_OK && Tp >= T, "winograd4_input: bad shape");
     SSDHIP_REQUIRE((int64_t)N * H * W * C < (1ll << 31) && (int64_t)36 * Tp * C < (1ll << 33), "winograd4_input: tensor too large");
-    const int TH = (H + 3) / 4, TW = (W + 3) / 4, C4 = C / 4;
-    const int64_t total = (int64_t)T * C4;
-    dim3 grid(cdiv(total, 256)), block(256);
+    const int TH = (H + 3) / 4, TW = (W + 3) / 4;
     hipStream_t st = (hipStream_t)stream;
-    if (in_scale)
-        hipLaunchKernelGGL(winograd4_input_kernel<true>, grid, block, 0, st, reinterpret_cast<const float4*>(x),
-                           reinterpret_cast<const float4*>(in_scale), reinterpret_cast<const float4*>(in_shift),
-                           reinterpret_cast<float4*>(V), H, W, C4, TH, TW, T, Tp);
-    else
-        hipLaunchKernelGGL(winograd4_input_kernel<false>, grid, block, 0, st, reinterpret_cast<const float4*>(x), nullptr, nullptr,
-                           reinterpret_cast<float4*>(V), H, W, C4, TH, TW, T, Tp);
+    int vec = 2;
+#ifdef SSDHIP_PROBES
+    if (const char* e = getenv("SSDHIP_W4_VEC")) vec = atoi(e) == 4 ? 4 : 2;      // A/B: float4 per thread
+#endif
+    const int CV = C / vec;
+    const int64_t total = (int64_t)T * CV;
+    dim3 grid(cdiv(total, 256)), block(256);
+    if (vec == 4) {
+        if (in_scale)
+            hipLaunchKernelGGL((winograd4_input_kernel<true, float4>), grid, block, 0, st, reinterpret_cast<const float4*>(x),
+                               reinterpret_cast<const float4*>(in_scale), reinterpret_cast<const float4*>(in_shift),
+                               reinterpret_cast<float4*>(V), H, W, CV, TH, TW, T, Tp);
+        else
+            hipLaunchKernelGGL((winograd4_input_kernel<false, float4>), grid, block, 0, st, reinterpret_cast<const float4*>(x), nullptr, nullptr,
+                               reinterpret_cast<float4*>(V), H, W, CV, TH, TW, T, Tp);
+    } else {
+        if (in_scale)
+            hipLaunchKernelGGL((winograd4_input_kernel<true, float2>), grid, block, 0, st, reinterpret_cast<const float2*>(x),
+                               reinterpret_cast<const float2*>(in_scale), reinterpret_cast<const float2*>(in_shift),
+                               reinterpret_cast<float2*>(V), H, W, CV, TH, TW, T, Tp);
+        else
+            hipLaunchKernelGGL((winograd4_input_kernel<false, float2>), grid, block, 0, st, reinterpret_cast<const float2*>(x), nullptr, nullptr,
+                               reinterpret_cast<float2*>(V), H, W, CV, TH, TW, T, Tp);
+    }
     SSDHIP_CHECK_LAUNCH();
     return SSDHIP_OK;
 }

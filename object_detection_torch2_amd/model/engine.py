@@ -296,10 +296,13 @@ class Engine:
         p.x, p.w, p.y, p.N = x0, w0, y0, planes
 
     def _wino4_ok(self, c, g, sizing=False):
-        """Layers on the Winograd F(4x4,3x3) passes: frozen (forward only: no gradient is computed from or through them), 3x3/s1/p1,
-        K = Cin >= 256 (the transforms move 2.25x the activation bytes each way: they pay for themselves from K = 256 on), maps of
-        8 .. 80 px (conv_3_2 .. conv_5_3 of SSD300: 75, 38, 19 px; 64 and 32 px of SSD512); fp32 mode only."""
-        return (self._wino_mode == 'f4' and (sizing or not self.bf16) and c.frozen and not c.is_head and c.k == 3 and c.stride == 1 and c.pad == 1
+        """Layers on the Winograd F(4x4,3x3) passes: forward of the frozen backbone's 3x3/s1/p1 layers and of the first trainable layer
+        on top of it (conv_6_1: its weight gradient reads the backbone's activation and dz, not the forward's products; no data gradient
+        is taken through it), K = Cin >= 256 (the transforms move 2.25x the activation bytes each way: they pay for themselves from
+        K = 256 on), maps of 8 .. 80 px (conv_3_2 .. conv_6_1 of SSD300: 75, 38, 19 px; 64 and 32 px of SSD512); fp32 mode only."""
+        first_tail = 0 < self.tail_start < len(self.stages) and c is self.stages[self.tail_start].conv
+        return (self._wino_mode == 'f4' and (sizing or not self.bf16) and (c.frozen or first_tail) and not c.is_head
+                and c.k == 3 and c.stride == 1 and c.pad == 1
                 and c.cin >= 256 and c.cin % 32 == 0 and c.cout % 4 == 0 and 256 % (c.cout // 4) == 0
                 and 8 <= min(g['hi'], g['wi']) and max(g['hi'], g['wi']) <= 80)
 
@@ -554,7 +557,9 @@ class Engine:
                     for spec in (s.conv, s.head):
                         if spec is None or spec.frozen:
                             continue
-                        if not self.bf16 and ((spec.wino and self._wino_ok(g)) or (spec.is_head and i in b['head_v'])):
+                        if self._wino4_ok(spec, g):
+                            self._wino4_weights(spec)
+                        elif not self.bf16 and ((spec.wino and self._wino_ok(g)) or (spec.is_head and i in b['head_v'])):
                             self._wino_weights(spec)
                         else:
                             self._pack(spec)
