@@ -122,6 +122,10 @@ int ssdhip_winograd4_input(const float* x, const float* in_scale, const float* i
 int ssdhip_winograd4_stat_rows(int N, int H, int W, int Cout);
 int ssdhip_winograd4_output(const float* M, const float* bias, float* y, float* stats, int N, int H, int W, int Cout, int Tp,
                             void* stream);
+/* detector heads (as ssdhip_winograd_output_head): M planes have Cp = Cout padded to 32 channels; y is the (N, P, 4+C) prediction
+ * tensor at the head's prior offset (model/ssd.py:103-104) */
+int ssdhip_winograd4_output_head(const float* M, const float* bias, float* y, int64_t y_batch_stride, int N, int H, int W, int Cout,
+                                 int Cp, int Tp, void* stream);
 
 /* ---- A4  nn.BatchNorm2d, training=True (model/vgg16.py:34, model/ssd.py:62) -----------------------------
  * partial (MB,C,2) -> scale = gamma*rsqrt(var+eps), shift = beta-mean*scale (biased var); running stats EMA with
@@ -204,6 +208,10 @@ int ssdhip_conv2d_wgrad(const ssdhip_wgrad_params* p, void* stream);
  * 16 plane products dU = dM^T V on the wgrad MFMA kernel (2.25x fewer flops), dW = G^T dU G.  dy must be dense.     */
 int64_t ssdhip_conv2d_wgrad_winograd_ws_bytes(const ssdhip_wgrad_params* p);
 int ssdhip_conv2d_wgrad_winograd(const ssdhip_wgrad_params* p, void* stream);
+/* the same through Winograd F(4x4,3x3) (36 planes of a quarter as many tiles: 1.78x fewer MFMA flops; dW = G^T dU G in fp64):
+ * p->wino_v, when set, is the forward's F(4x4) input transform of the same activation with planes padded to 128 rows */
+int64_t ssdhip_conv2d_wgrad_winograd4_ws_bytes(const ssdhip_wgrad_params* p);
+int ssdhip_conv2d_wgrad_winograd4(const ssdhip_wgrad_params* p, void* stream);
 
 /* BatchNorm2d(train)+ReLU backward.  z raw conv output (M,C); da grad w.r.t. relu output.
  * pass 1: partial sums of dy=da*(z*scale+shift>0) and dy*xhat -> (MB,C,2);  pass 2 (after finalize):

@@ -59,6 +59,7 @@ SIGNATURES = {
     'ssdhip_winograd4_input': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ssdhip_winograd4_stat_rows': (c_int, [c_int, c_int, c_int, c_int]),
     'ssdhip_winograd4_output': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'ssdhip_winograd4_output_head': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ssdhip_bn_finalize': (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'ssdhip_bn_fold_eval': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),
@@ -80,6 +81,8 @@ SIGNATURES = {
     'ssdhip_conv2d_wgrad': (c_int, [POINTER(WgradParams), c_void_p]),
     'ssdhip_conv2d_wgrad_winograd_ws_bytes': (c_int64, [POINTER(WgradParams)]),
     'ssdhip_conv2d_wgrad_winograd': (c_int, [POINTER(WgradParams), c_void_p]),
+    'ssdhip_conv2d_wgrad_winograd4_ws_bytes': (c_int64, [POINTER(WgradParams)]),
+    'ssdhip_conv2d_wgrad_winograd4': (c_int, [POINTER(WgradParams), c_void_p]),
     'ssdhip_bn_relu_bwd_reduce': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                           c_void_p, c_int, c_void_p]),
     'ssdhip_bn_relu_bwd_finalize': (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

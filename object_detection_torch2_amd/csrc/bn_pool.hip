@@ -71,21 +71,44 @@ __device__ __forceinline__ void bn_finalize_channel(double s1, double s2, int c,
     }
 }
 
-// one launch for small partial tables: block = 32 channels x 8 row-lanes, loops over all MB rows, finalizes in place
-__global__ __launch_bounds__(256) void bn_stats_fused(const float* __restrict__ partial, int MB, int C, double count,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
-                                                       float eps, float* __restrict__ scale, float* __restrict__ shift,
-                                                       float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+// one launch for small partial tables: block = 32 channels x 32 row-lanes (1,024 threads), loops over all MB rows, finalizes in place
+__global__ __launch_bounds__(1024) void bn_stats_fused(const float* __restrict__ partial, int MB, int C, double count,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+                                                        float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                                        float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+    __shared__ double red[32][32][2];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int r = rl; r < MB; r += 32) {
+            float2 v = *reinterpret_cast<const float2*>(partial + ((size_t)r * C + c) * 2);
+            s1 += (double)v.x;
+            s2 += (double)v.y;
+        }
+    red[rl][cl][0] = s1; red[rl][cl][1] = s2;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        for (int k = 1; k < 32; ++k) { s1 += red[k][cl][0]; s2 += red[k][cl][1]; }
+        bn_finalize_channel(s1, s2, c, count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd);
+    }
+}
+
+// stage 2: block = 32 channels x 8 split-lanes (the former one-thread-per-channel loop walked up to 64 dependent fp64 loads: 17 us on the
+// critical path of every backbone layer); fixed summation order: lane k takes splits k, k + 8, ..., lanes are added 0..7
+__global__ __launch_bounds__(256) void bn_stats_stage2(const double* __restrict__ ws, int split, int C, double count, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                        float momentum, float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                                        float* __restrict__ save_mean, float* __restrict__ save_invstd) {
     __shared__ double red[8][32][2];
     const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C)
-        for (int r = rl; r < MB; r += 8) {
-            float2 v = *reinterpret_cast<const float2*>(partial + ((size_t)r * C + c) * 2);
-            s1 += (double)v.x;
-            s2 += (double)v.y;
+        for (int s = rl; s < split; s += 8) {
+            const double2 v = *reinterpret_cast<const double2*>(ws + ((size_t)s * C + c) * 2);
+            s1 += v.x; s2 += v.y;
         }
     red[rl][cl][0] = s1; red[rl][cl][1] = s2;
     __syncthreads();
@@ -94,17 +117,6 @@ __global__ __launch_bounds__(256) void bn_stats_fused(const float* __restrict__ 
         for (int k = 1; k < 8; ++k) { s1 += red[k][cl][0]; s2 += red[k][cl][1]; }
         bn_finalize_channel(s1, s2, c, count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd);
     }
-}
-
-__global__ void bn_stats_stage2(const double* __restrict__ ws, int split, int C, double count, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
-                                float momentum, float eps, float* __restrict__ scale, float* __restrict__ shift,
-                                float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int s = 0; s < split; ++s) { s1 += ws[((size_t)s * C + c) * 2]; s2 += ws[((size_t)s * C + c) * 2 + 1]; }
-    bn_finalize_channel(s1, s2, c, count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd);
 }
 
 __global__ void bn_fold_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
@@ -310,7 +322,7 @@ int ssdhip_bn_finalize(const float* partial, int MB, int C, int64_t count, const
     SSDHIP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats go together");
     hipStream_t st = (hipStream_t)stream;
     if ((int64_t)MB * 8 <= 4096) {      // <= 512 rows per row-lane: one launch, same fp64 summation order class (fixed order)
-        hipLaunchKernelGGL(bn_stats_fused, dim3(cdiv(C, 32)), dim3(256), 0, st, partial, MB, C, (double)count, gamma, beta, running_mean,
+        hipLaunchKernelGGL(bn_stats_fused, dim3(cdiv(C, 32)), dim3(1024), 0, st, partial, MB, C, (double)count, gamma, beta, running_mean,
                            running_var, momentum, eps, scale, shift, save_mean, save_invstd);
         SSDHIP_CHECK_LAUNCH();
         return SSDHIP_OK;
@@ -318,7 +330,7 @@ int ssdhip_bn_finalize(const float* partial, int MB, int C, int64_t count, const
     const int split = stats_split(MB, C);
     hipLaunchKernelGGL(bn_stats_stage1, dim3(cdiv(C, 32), split), dim3(256), 0, st, partial, MB, C, split, ws);
     SSDHIP_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_stats_stage2, dim3(cdiv(C, 64)), dim3(64), 0, st, ws, split, C, (double)count, gamma, beta, running_mean,
+    hipLaunchKernelGGL(bn_stats_stage2, dim3(cdiv(C, 32)), dim3(256), 0, st, ws, split, C, (double)count, gamma, beta, running_mean,
                        running_var, momentum, eps, scale, shift, save_mean, save_invstd);
     SSDHIP_CHECK_LAUNCH();
     return SSDHIP_OK;

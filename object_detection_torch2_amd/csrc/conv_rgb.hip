@@ -43,15 +43,22 @@ __global__ __launch_bounds__(256) void conv_rgb3x3_kernel(const float4* __restri
         const int n = (int)(pc / ((int64_t)H * W));
         const int rem = (int)(pc - (int64_t)n * H * W);
         const int y = rem / W, xx = rem - y * W;
+        // five unconditional loads (addresses clamped into the image) issued back to back, zeroed afterwards where the tap lies
+        // outside: loads under `ok ? load : 0` compile to exec-masked load / wait pairs, one memory latency each
         float4 a[5];
+        bool ok[5];
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
             const int t = 2 * q + half;
             const int r = t / 3, s = t - 3 * r;
             const int yy = y + r - 1, xs = xx + s - 1;
-            const bool ok = pv && t < 9 && (unsigned)yy < (unsigned)H && (unsigned)xs < (unsigned)W;
-            a[q] = ok ? x[((size_t)n * H + yy) * W + xs] : make_float4(0.f, 0.f, 0.f, 0.f);
+            ok[q] = pv && t < 9 && (unsigned)yy < (unsigned)H && (unsigned)xs < (unsigned)W;
+            const int yc = min(max(yy, 0), H - 1), xc = min(max(xs, 0), W - 1);
+            a[q] = x[((size_t)n * H + yc) * W + xc];
         }
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+            if (!ok[q]) a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         f32x16 acc[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j)

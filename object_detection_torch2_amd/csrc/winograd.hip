@@ -23,7 +23,13 @@ template <bool XFORM>
 __global__ __launch_bounds__(256) void winograd_input_kernel(const float4* __restrict__ x, const float4* __restrict__ scale,
                                                              const float4* __restrict__ shift, float4* __restrict__ V, int H, int W,
                                                              int C4, int TH, int TW, int T, int Tp) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // every XCD (own L2) takes a contiguous eighth of the tiles: neighbouring tiles share half of their 4x4 patches
+    int bid;
+    {
+        const int nb = gridDim.x, xcd = blockIdx.x & 7, local = blockIdx.x >> 3, q8 = nb >> 3, r8 = nb & 7;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+    }
+    const int64_t idx = (int64_t)bid * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)T * C4) return;
     const int c4 = (int)(idx % C4);
     const int t = (int)(idx / C4);
@@ -33,22 +39,31 @@ __global__ __launch_bounds__(256) void winograd_input_kernel(const float4* __res
     const int n = q / TH;
     float4 sc, sh;
     if (XFORM) { sc = scale[c4]; sh = shift[c4]; }
+    // 16 unconditional loads (addresses clamped into the image) issued back to back, then activation and the zero padding after it
+    // on the registers: loads inside `if (inside)` blocks compile to one exec-masked load / wait / activate sequence per position
     float4 d[4][4];
+    const float4* xn = x + (size_t)n * H * W * C4 + c4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int h = 2 * th - 1 + i;
+        const int h = min(max(2 * th - 1 + i, 0), H - 1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int w = 2 * tw - 1 + j;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
-                v = x[((size_t)(n * H + h) * W + w) * C4 + c4];
-                if (XFORM) {
-                    v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-                    v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
-                }
+            const int w = min(max(2 * tw - 1 + j, 0), W - 1);
+            d[i][j] = xn[(size_t)(h * W + w) * C4];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool hin = (unsigned)(2 * th - 1 + i) < (unsigned)H;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool in = hin && (unsigned)(2 * tw - 1 + j) < (unsigned)W;
+            float4 v = d[i][j];
+            if (XFORM) {
+                v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+                v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
             }
-            d[i][j] = v;
+            d[i][j] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     // B^T d : rows (d0-d2, d1+d2, d2-d1, d1-d3), then the same on columns

@@ -213,6 +213,52 @@ __global__ __launch_bounds__(256) void winograd4_output_kernel(const float4* __r
     }
 }
 
+// Detector-head output transform: M (36, Tp, Cp) with Cp = Cout padded to 32 -> y[n*y_batch_stride + (h*W + w)*Cout + co]
+// (the (N, P, 4+C) prediction tensor: zero-copy concat of model/ssd.py:103-104), + bias.  One thread = one tile x 4 channels.
+__global__ __launch_bounds__(256) void winograd4_output_head_kernel(const float4* __restrict__ Mo, const float* __restrict__ bias,
+                                                                    float* __restrict__ y, long long y_batch_stride, int H, int W,
+                                                                    int Cout, int Cp4, int TH, int TW, int T, int Tp) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)T * Cp4) return;
+    const int c4 = (int)(idx % Cp4);
+    const int t = (int)(idx / Cp4);
+    if (c4 * 4 >= Cout) return;
+    const int tw = t % TW;
+    const int q = t / TW;
+    const int th = q % TH;
+    const int n = q / TH;
+    const size_t plane = (size_t)Tp * Cp4;
+    const float4* mp = Mo + (size_t)t * Cp4 + c4;
+    float4 r[4][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float4 m[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) m[i] = mp[(size_t)(6 * i + j) * plane];
+        at6(m[0], m[1], m[2], m[3], m[4], m[5], r[0][j], r[1][j], r[2][j], r[3][j]);
+    }
+    float bv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bv[k] = (bias && c4 * 4 + k < Cout) ? bias[c4 * 4 + k] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int h = 4 * th + a;
+        float4 o[4];
+        at6(r[a][0], r[a][1], r[a][2], r[a][3], r[a][4], r[a][5], o[0], o[1], o[2], o[3]);
+        if (h >= H) continue;
+#pragma unroll
+        for (int b2 = 0; b2 < 4; ++b2) {
+            const int w = 4 * tw + b2;
+            if (w >= W) continue;
+            float* dst = y + (size_t)n * y_batch_stride + (size_t)(h * W + w) * Cout + c4 * 4;
+            const float ov[4] = {o[b2].x + bv[0], o[b2].y + bv[1], o[b2].z + bv[2], o[b2].w + bv[3]};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (c4 * 4 + k < Cout) dst[k] = ov[k];
+        }
+    }
+}
+
 // U[xi][co][ci] = (G g G^T)[xi] in fp64, rounded once
 __global__ void winograd4_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int rows_pad, int KP) {
     const int64_t total = (int64_t)rows_pad * KP;
@@ -329,6 +375,18 @@ int ssdhip_winograd4_output(const float* Mo, const float* bias, float* y, float*
                        H, W, Cout / 4, TH, TW, T, Tp, tb);
     SSDHIP_CHECK_LAUNCH();
     return cdiv(T, tb);      // rows of the BN partial table
+}
+
+int ssdhip_winograd4_output_head(const float* Mo, const float* bias, float* y, int64_t y_batch_stride, int N, int H, int W, int Cout,
+                                 int Cp, int Tp, void* stream) {
+    SSDHIP_REQUIRE(Mo && y && Cout > 0 && Cp >= Cout && Cp % 4 == 0, "winograd4_output_head: bad arguments");
+    int T, Tp128;
+    SSDHIP_REQUIRE(ssdhip_winograd4_tiles(N, H, W, 128, &T, &Tp128) == SSDHIP_OK && Tp >= T, "winograd4_output_head: bad shape");
+    const int TH = (H + 3) / 4, TW = (W + 3) / 4, Cp4 = Cp / 4;
+    hipLaunchKernelGGL(winograd4_output_head_kernel, dim3(cdiv((int64_t)T * Cp4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(Mo), bias, y, (long long)y_batch_stride, H, W, Cout, Cp4, TH, TW, T, Tp);
+    SSDHIP_CHECK_LAUNCH();
+    return SSDHIP_OK;
 }
 
 }  // extern "C"

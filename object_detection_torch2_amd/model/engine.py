@@ -190,10 +190,17 @@ class Engine:
                 offs.append(p)
                 p += g['ho'] * g['wo'] * s.head.anchors
         b['head_off'], b['P'] = offs, p
-        b['head_v'] = {}
+        b['head_v'], b['head_f4'] = {}, set()
         head_m = 0
         for i, (s, g) in enumerate(zip(self.stages, geo)):
             if s.head is not None and s.head.wino_head and min(g['ho'], g['wo']) >= 10:
+                if self._wgrad_wino4(s.head, g['ho'], g['wo']):
+                    # heads on >= 16-px maps: forward AND weight gradient through F(4x4), sharing one input transform V (planes of 128-row multiples)
+                    tp = _rup(N * ((g['ho'] + 3) // 4) * ((g['wo'] + 3) // 4), 128)
+                    b['head_v'][i] = torch.empty(36 * tp * s.head.cin, **f)
+                    b['head_f4'].add(i)
+                    head_m = max(head_m, 36 * tp * s.head.co_pad)
+                    continue
                 tp = (N * ((g['ho'] + 1) // 2) * ((g['wo'] + 1) // 2) + 127) // 128 * 128
                 b['head_v'][i] = torch.empty(16 * tp * s.head.cin, **f)
                 head_m = max(head_m, 16 * tp * s.head.co_pad)     # own workspace: the heads run on the side stream
@@ -318,11 +325,12 @@ class Engine:
     def _wino4_weights(self, spec):
         w, _ = self._weight(spec)
         key = (w.data_ptr(), w._version, self.m._hip_epoch if not spec.frozen else 0)
+        rows = spec.rows_pad if not spec.is_head else _rup(spec.co_pad, 128)
         if spec.wino4_u is None or spec.wino4_u.device != w.device:
-            spec.wino4_u = torch.empty(36 * spec.rows_pad * spec.cin, device=w.device, dtype=torch.float32)
+            spec.wino4_u = torch.empty(36 * rows * spec.cin, device=w.device, dtype=torch.float32)
             spec.wino4_key = None
         if spec.wino4_key != key:
-            _lib.check(self.lib.ssdhip_winograd4_weight(_lib.ptr(w), _lib.ptr(spec.wino4_u), spec.cout, spec.cin, spec.rows_pad, spec.cin,
+            _lib.check(self.lib.ssdhip_winograd4_weight(_lib.ptr(w), _lib.ptr(spec.wino4_u), spec.cout, spec.cin, rows, spec.cin,
                                                         _lib.stream()), 'winograd4_weight')
             spec.wino4_key = key
         return spec.wino4_u
@@ -392,6 +400,27 @@ class Engine:
                                   flops=2.0 * 16 * tp * spec.cin * spec.cout, e0=e0, e1=e1))
         return _lib.check(L.ssdhip_winograd_output(_lib.ptr(Mo), _lib.ptr(bias), _lib.ptr(z), _lib.ptr(stats), N, h, w, spec.cout, st),
                           f'winograd_output {spec.name}')
+
+    def _head_winograd4(self, spec, x, xs, V, b, out_ptr, out_batch_stride, N, h, w):
+        """Detector head forward through Winograd F(4x4,3x3); V stays valid for the F(4x4) weight gradient in backward."""
+        L, st = self.lib, _lib.stream()
+        U = self._wino4_weights(spec)
+        _, bias = self._weight(spec)
+        Mo = b['head_m']
+        tp = _rup(N * ((h + 3) // 4) * ((w + 3) // 4), 128)
+        _lib.check(L.ssdhip_winograd4_input(_lib.ptr(x), _lib.ptr(xs[0]) if xs is not None else None,
+                                            _lib.ptr(xs[1]) if xs is not None else None, _lib.ptr(V), N, h, w, spec.cin, tp, st), f'winograd4_input {spec.name}')
+        cp = spec.co_pad
+        rows = _rup(cp, 128)
+        p = _lib.ConvParams()
+        p.x, p.w, p.y, p.y_batch_stride = V.data_ptr(), U.data_ptr(), Mo.data_ptr(), tp * cp
+        p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout = 36, 1, tp, spec.cin, 1, tp, cp
+        p.R, p.S, p.stride, p.pad, p.KP, p.mode, p.accumulate = 1, 1, 1, 0, spec.cin, 0, 0
+        p.tile = 128128 if cp <= 128 else 128064
+        p.rows_per_img, p.w_img_stride = tp, rows * spec.cin
+        self._plane_gemm(p, tp, spec.cin, cp, rows * spec.cin, f'winograd4 gemm {spec.name}', planes=36)
+        _lib.check(L.ssdhip_winograd4_output_head(_lib.ptr(Mo), _lib.ptr(bias), out_ptr, out_batch_stride, N, h, w, spec.cout, cp, tp, st),
+                   f'winograd4_output_head {spec.name}')
 
     def _head_winograd(self, spec, x, xs, V, b, out_ptr, out_batch_stride, N, h, w):
         """Detector head forward through Winograd; V (input transform of the head's activation) stays valid for backward."""
@@ -557,7 +586,7 @@ class Engine:
                     for spec in (s.conv, s.head):
                         if spec is None or spec.frozen:
                             continue
-                        if self._wino4_ok(spec, g):
+                        if self._wino4_ok(spec, g) or (spec.is_head and i in b['head_f4'] and not self.bf16):
                             self._wino4_weights(spec)
                         elif not self.bf16 and ((spec.wino and self._wino_ok(g)) or (spec.is_head and i in b['head_v'])):
                             self._wino_weights(spec)
@@ -723,7 +752,10 @@ class Engine:
                 if s.head is not None:
                     off = b['head_off'][s.head_index]
                     with fork.side(after=bb if on_bb else None):   # needs z and this stage's BN scale/shift only; writes its own rows of `out`
-                        if i in b['head_v'] and not self.bf16:
+                        if i in b['head_f4'] and not self.bf16:
+                            self._head_winograd4(s.head, z, act_xs, b['head_v'][i], b, ctypes.c_void_p(out.data_ptr() + off * self.row * 4),
+                                                 b['P'] * self.row, N, g['ho'], g['wo'])
+                        elif i in b['head_v'] and not self.bf16:
                             self._head_winograd(s.head, z, act_xs, b['head_v'][i], b, ctypes.c_void_p(out.data_ptr() + off * self.row * 4),
                                                 b['P'] * self.row, N, g['ho'], g['wo'])
                         else:
@@ -795,6 +827,8 @@ class Engine:
                 ws_bytes = max(ws_bytes, _lib.check(self.lib.ssdhip_conv2d_wgrad_ws_bytes(ctypes.byref(p)), 'wgrad_ws_bytes'))    # direct (bf16 mode: always)
                 if self._wgrad_wino(spec, hi, wi):
                     ws_bytes = max(ws_bytes, _lib.check(self.lib.ssdhip_conv2d_wgrad_winograd_ws_bytes(ctypes.byref(p)), 'wgrad_ws_bytes'))
+                if self._wgrad_wino4(spec, hi, wi):
+                    ws_bytes = max(ws_bytes, _lib.check(self.lib.ssdhip_conv2d_wgrad_winograd4_ws_bytes(ctypes.byref(p)), 'wgrad_ws_bytes'))
         bw['wgrad_ws'] = torch.empty((ws_bytes + 3) // 4, **f)
         dg_v = dg_m = 0             # Winograd data gradients (un-frozen backbone): dy planes V and dx planes M
         for i in range(self.tail_start + 1, len(self.stages)):
@@ -806,6 +840,11 @@ class Engine:
         bw['dg_m'] = torch.empty(dg_m, **f) if dg_m else None
         b['bwd'] = bw
         return bw
+
+    def _wgrad_wino4(self, spec, hi, wi):
+        """Winograd F(4x4,3x3) weight gradient (36 planes of a quarter as many tiles, dW = G^T dU G in fp64: error against fp64 3.6e-7 ..
+        8.5e-7 of max |dW|, the class of the F(2x2) form and of torch's fp32): conv_6_1 and the heads on >= 16-px maps."""
+        return self._wino_mode == 'f4' and self._wgrad_wino(spec, hi, wi) and min(hi, wi) >= 16
 
     @staticmethod
     def _wgrad_wino(spec, hi, wi):
@@ -836,7 +875,12 @@ class Engine:
         p.ws = bw['wgrad_ws'].data_ptr()
         # bf16 mode: operands rounded to bf16 at staging, 16x the matrix rate -- the direct kernel outruns the fp32 Winograd form
         p.compute = int(self.bf16)
-        fn = self.lib.ssdhip_conv2d_wgrad_winograd if (self._wgrad_wino(spec, hi, wi) and not self.bf16) else self.lib.ssdhip_conv2d_wgrad
+        if self._wgrad_wino4(spec, hi, wi) and not self.bf16:
+            fn = self.lib.ssdhip_conv2d_wgrad_winograd4      # heads: wino_v is the forward's F(4x4) input transform (_buffers: head_f4)
+        elif self._wgrad_wino(spec, hi, wi) and not self.bf16:
+            fn = self.lib.ssdhip_conv2d_wgrad_winograd
+        else:
+            fn = self.lib.ssdhip_conv2d_wgrad
         _lib.check(fn(ctypes.byref(p), _lib.stream()), f'wgrad {spec.name}')
 
     def _dgrad_wino(self, spec, g):

@@ -233,7 +233,7 @@ def conv2d_dgrad(dy, w_oihw, in_hw, stride=1, pad=0, accumulate_into=None, tile=
 
 
 def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, in_scale=None, in_shift=None, want_bias=True, winograd=False, bf16=False):
-    """x (N,Hi,Wi,Cin), dy (N,Ho,Wo,dy_row>=Cout) -> (dW OIHW, db or None).  winograd=True: F(2x2,3x3) path (3x3/s1/p1).
+    """x (N,Hi,Wi,Cin), dy (N,Ho,Wo,dy_row>=Cout) -> (dW OIHW, db or None).  winograd=True: F(2x2,3x3) path (3x3/s1/p1); winograd=4: F(4x4,3x3).
     bf16 (direct path only): operands rounded to bf16 at staging, bf16 MFMA with fp32 accumulate, fp32 result."""
     _lib.require_gpu(x, dy)
     lib = _lib.load()
@@ -253,8 +253,11 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, in_scale=None, in_shift=None, 
     if bf16 and winograd:
         raise ValueError('conv2d_wgrad: the bf16 weight gradient is the direct kernel (no Winograd form)')
     p.compute = int(bf16)
-    fn_ws, fn = (lib.ssdhip_conv2d_wgrad_winograd_ws_bytes, lib.ssdhip_conv2d_wgrad_winograd) if winograd else \
-        (lib.ssdhip_conv2d_wgrad_ws_bytes, lib.ssdhip_conv2d_wgrad)
+    if winograd == 4 and not isinstance(winograd, bool):      # F(4x4,3x3)
+        fn_ws, fn = lib.ssdhip_conv2d_wgrad_winograd4_ws_bytes, lib.ssdhip_conv2d_wgrad_winograd4
+    else:
+        fn_ws, fn = (lib.ssdhip_conv2d_wgrad_winograd_ws_bytes, lib.ssdhip_conv2d_wgrad_winograd) if winograd else \
+            (lib.ssdhip_conv2d_wgrad_ws_bytes, lib.ssdhip_conv2d_wgrad)
     ws = torch.empty((_lib.check(fn_ws(ctypes.byref(p)), 'wgrad_ws_bytes') + 3) // 4, device=x.device, dtype=torch.float32)
     p.ws = ws.data_ptr()
     _lib.check(fn(ctypes.byref(p), _lib.stream()), 'conv2d_wgrad')

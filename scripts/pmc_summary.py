@@ -31,7 +31,7 @@ for k, d in out.items():
         # busy cycles are summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs
         e['mfma_pipe_util'] = d['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / (d['GRBM_GUI_ACTIVE'] / 8)
     res[k] = e
-json.dump(res, open(os.path.join(root, 'profiles', 'r02_pmc_summary.json'), 'w'), indent=1, sort_keys=True)
+json.dump(res, open(os.path.join(root, 'profiles', os.environ.get('PMC_OUT', 'r03_pmc_summary.json')), 'w'), indent=1, sort_keys=True)
 for k in sorted(res, key=lambda k: -res[k].get('hbm_bytes_per_launch', 0))[:14]:
     e = res[k]
     print(f"{k[:70]:70s} hbm/launch {e.get('hbm_bytes_per_launch', 0)/1e6:9.2f} MB  mfma_util {e.get('mfma_pipe_util', 0):.3f}  lds_conflict {e.get('SQ_LDS_BANK_CONFLICT', 0):.3g}")

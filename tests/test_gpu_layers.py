@@ -374,3 +374,13 @@ def test_wgrad_winograd(case):
     dw2, _ = ops.conv2d_wgrad(ops.to_nhwc(zprev.to(DEV)), ops.to_nhwc(dy.to(DEV), pad_to=cpad), tuple(w.shape), pad=1,
                               in_scale=scale.to(DEV), in_shift=shift.to(DEV))
     assert rel_err(dw.cpu(), dw2.cpu()) < 5e-5           # Winograd and direct wgrad agree
+    # F(4x4,3x3) form (csrc/conv_wgrad.hip: 36 planes, dW = G^T dU G in fp64): same bounds
+    dw4, db4 = ops.conv2d_wgrad(ops.to_nhwc(zprev.to(DEV)), ops.to_nhwc(dy.to(DEV), pad_to=cpad), tuple(w.shape), pad=1,
+                                in_scale=scale.to(DEV), in_shift=shift.to(DEV), winograd=4)
+    assert rel_err(dw4.cpu(), w.grad) < 5e-5
+    assert rel_err(db4.cpu(), b.grad) < 2e-5
+    w64 = w.detach().double().requires_grad_(True)
+    F.conv2d(a.double(), w64, None, padding=1).backward(dy.double())
+    e4, e2, e32 = rel_err(dw4.cpu().double(), w64.grad), rel_err(dw.cpu().double(), w64.grad), rel_err(w.grad.double(), w64.grad)
+    print(f'wgrad {case}: max err / max |dW| vs fp64: F(4x4) {e4:.2e}, F(2x2) {e2:.2e}, torch fp32 {e32:.2e}')
+    assert e4 < 1e-5
