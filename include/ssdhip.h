@@ -120,8 +120,13 @@ int ssdhip_winograd4_weight(const float* w_oihw, float* U, int Cout, int Cin, in
 int ssdhip_winograd4_input(const float* x, const float* in_scale, const float* in_shift, float* V, int N, int H, int W, int C, int Tp,
                            void* stream);
 int ssdhip_winograd4_stat_rows(int N, int H, int W, int Cout);
-int ssdhip_winograd4_output(const float* M, const float* bias, float* y, float* stats, int N, int H, int W, int Cout, int Tp,
-                            void* stream);
+/* accumulate != 0: y += result (data gradients: two producers of one activation gradient) */
+int ssdhip_winograd4_output(const float* M, const float* bias, float* y, float* stats, int accumulate, int N, int H, int W, int Cout,
+                            int Tp, void* stream);
+/* data gradient of the same layers (autograd backward of nn.Conv2d, train.py:121) = the ADJOINT convolution of dy through the same three
+ * passes: U (36, rows_pad >= Cin, KP >= Cout) from the filter flipped with its channel roles swapped; input = dy (N,H,W,KP), output
+ * dx (N,H,W,Cin) via ssdhip_winograd4_output(bias = stats = NULL) */
+int ssdhip_winograd4_weight_adjoint(const float* w_oihw, float* U, int Cout, int Cin, int rows_pad, int KP, void* stream);
 /* detector heads (as ssdhip_winograd_output_head): M planes have Cp = Cout padded to 32 channels; y is the (N, P, 4+C) prediction
  * tensor at the head's prior offset (model/ssd.py:103-104) */
 int ssdhip_winograd4_output_head(const float* M, const float* bias, float* y, int64_t y_batch_stride, int N, int H, int W, int Cout,

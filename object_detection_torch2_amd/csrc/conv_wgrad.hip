@@ -513,37 +513,65 @@ __global__ __launch_bounds__(256) void winograd4_outgrad_kernel(const float4* __
     }
 }
 
-// dW[co][ci][3][3] = G^T (sum_split dU) G in fp64; slabs ws[split][co][xi][ci]
-__global__ void winograd4_wgrad_output_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int CoutT, int CinT,
-                                              int splitK) {
-    const int64_t total = (int64_t)Cout * Cin;
+// dW[co][ci][3][3] = G^T (sum_split dU) G in fp64; slabs ws[split][co][xi][ci].  One thread = one output channel x 2 input channels:
+// the 36 * splitK slab reads are independent 8-B loads (the one-channel form with the split loop innermost ran at 2 TB/s: 75 us for
+// conv_6_1's 150 MB of slabs)
+__global__ __launch_bounds__(256) void winograd4_wgrad_output_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin,
+                                                                     int CoutT, int CinT, int splitK) {
+    const int Cin4 = (Cin + 1) / 2;
+    const int64_t total = (int64_t)Cout * Cin4;
     const size_t slab = (size_t)CoutT * 36 * CinT;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int ci = (int)(i % Cin), co = (int)(i / Cin);
-        double t[3][6];                               // G^T u, column by column as the planes are summed
+        const int c4 = (int)(i % Cin4), co = (int)(i / Cin4);
+        const int ci = c4 * 2;
+        double u[36][2];
 #pragma unroll
-        for (int b = 0; b < 6; ++b) {
-            double u[6];
+        for (int xi = 0; xi < 36; ++xi)
 #pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                const size_t src = ((size_t)co * 36 + 6 * a + b) * CinT + ci;
-                double v = 0.0;
-                for (int s = 0; s < splitK; ++s) v += (double)ws[s * slab + src];
-                u[a] = v;
+            for (int k = 0; k < 2; ++k) u[xi][k] = 0.0;
+        for (int s = 0; s < splitK; ++s) {
+            const float* base = ws + s * slab + (size_t)co * 36 * CinT + ci;          // CinT is a multiple of 2: 8-B aligned
+#pragma unroll
+            for (int xi = 0; xi < 36; ++xi) {
+                const float2 v = *reinterpret_cast<const float2*>(base + (size_t)xi * CinT);
+                u[xi][0] += (double)v.x; u[xi][1] += (double)v.y;
             }
-            const double s12 = u[1] + u[2], d12 = u[1] - u[2], s34 = u[3] + u[4], d34 = u[3] - u[4];
-            t[0][b] = u[0] + (8.0 / 65.0) * s12 - (81.0 / 130.0) * s34;
-            t[1][b] = (12.0 / 65.0) * d12 - (27.0 / 65.0) * d34;
-            t[2][b] = (18.0 / 65.0) * (s12 - s34) + u[5];
         }
-        float* o = dw + ((size_t)co * Cin + ci) * 9;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const double s12 = t[r][1] + t[r][2], d12 = t[r][1] - t[r][2], s34 = t[r][3] + t[r][4], d34 = t[r][3] - t[r][4];
-            o[r * 3 + 0] = (float)(t[r][0] + (8.0 / 65.0) * s12 - (81.0 / 130.0) * s34);
-            o[r * 3 + 1] = (float)((12.0 / 65.0) * d12 - (27.0 / 65.0) * d34);
-            o[r * 3 + 2] = (float)((18.0 / 65.0) * (s12 - s34) + t[r][5]);
+        for (int k = 0; k < 2; ++k) {
+            if (ci + k >= Cin) break;
+            double t[3][6];                               // G^T u over the first plane index, then over the second
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const double s12 = u[6 + b][k] + u[12 + b][k], d12 = u[6 + b][k] - u[12 + b][k];
+                const double s34 = u[18 + b][k] + u[24 + b][k], d34 = u[18 + b][k] - u[24 + b][k];
+                t[0][b] = u[b][k] + (8.0 / 65.0) * s12 - (81.0 / 130.0) * s34;
+                t[1][b] = (12.0 / 65.0) * d12 - (27.0 / 65.0) * d34;
+                t[2][b] = (18.0 / 65.0) * (s12 - s34) + u[30 + b][k];
+            }
+            float* o = dw + ((size_t)co * Cin + ci + k) * 9;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const double s12 = t[r][1] + t[r][2], d12 = t[r][1] - t[r][2], s34 = t[r][3] + t[r][4], d34 = t[r][3] - t[r][4];
+                o[r * 3 + 0] = (float)(t[r][0] + (8.0 / 65.0) * s12 - (81.0 / 130.0) * s34);
+                o[r * 3 + 1] = (float)((12.0 / 65.0) * d12 - (27.0 / 65.0) * d34);
+                o[r * 3 + 2] = (float)((18.0 / 65.0) * (s12 - s34) + t[r][5]);
+            }
         }
+    }
+}
+
+// split-K slabs of the F(4x4) weight gradient summed in fixed order (fp64, one rounding) into slab 0: fully parallel and coalesced.  The heads
+// have few outputs and many splits (det_4_3: 51,200 weights, 12 slabs of 9.4 MB): summed inside the transform kernel that was 100 blocks
+// walking 432 loads each (70 us); as a pass of its own it is bandwidth-bound
+__global__ __launch_bounds__(256) void slab_sum_kernel(float4* __restrict__ ws, int64_t slab4, int splitK) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slab4; i += (int64_t)gridDim.x * blockDim.x) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        for (int s = 0; s < splitK; ++s) {
+            const float4 v = ws[s * slab4 + i];
+            a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+        }
+        ws[i] = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
     }
 }
 
@@ -749,11 +777,20 @@ int ssdhip_conv2d_wgrad_winograd4(const ssdhip_wgrad_params* p, void* stream) {
     SSDHIP_CHECK_LAUNCH();
     hipLaunchKernelGGL(wgrad_kernel<false>, dim3(a.CB * a.IB * a.taps * a.splitK), dim3(256), 0, st, a);
     SSDHIP_CHECK_LAUNCH();
-    int64_t total = (int64_t)p->Cout * p->Cin;
+    int splits_left = a.splitK;
+    if (a.splitK > 1) {
+        const int64_t slab4 = (int64_t)a.CoutT * 36 * a.CinT / 4;
+        int sb = (int)((slab4 + 255) / 256);
+        if (sb > 4096) sb = 4096;
+        hipLaunchKernelGGL(slab_sum_kernel, dim3(sb), dim3(256), 0, st, reinterpret_cast<float4*>(slabs), slab4, a.splitK);
+        SSDHIP_CHECK_LAUNCH();
+        splits_left = 1;
+    }
+    int64_t total = (int64_t)p->Cout * ((p->Cin + 1) / 2);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(winograd4_wgrad_output_kernel, dim3(blocks), dim3(256), 0, st, slabs, p->dw_oihw, p->Cout, p->Cin, a.CoutT, a.CinT,
-                       a.splitK);
+                       splits_left);
     SSDHIP_CHECK_LAUNCH();
     if (p->dbias) {
         float* partial = slabs + (size_t)a.splitK * a.CoutT * 36 * a.CinT;

@@ -153,7 +153,7 @@ __device__ __forceinline__ void at6(float4 m0, float4 m1, float4 m2, float4 m3, 
 // block = (256 / C4o) tile lanes x C4o channel quads; each block walks `tb` tiles and emits one row of BN partial sums
 __global__ __launch_bounds__(256) void winograd4_output_kernel(const float4* __restrict__ Mo, const float4* __restrict__ bias,
                                                                float4* __restrict__ y, float* __restrict__ stats, int H, int W, int C4o,
-                                                               int TH, int TW, int T, int Tp, int tb) {
+                                                               int TH, int TW, int T, int Tp, int tb, int accumulate) {
     __shared__ float red[256][8];
     const int lanesT = 256 / C4o;
     const int c4 = threadIdx.x % C4o, tl = threadIdx.x / C4o;
@@ -186,7 +186,8 @@ __global__ __launch_bounds__(256) void winograd4_output_kernel(const float4* __r
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     if (w0 + b < W) {
-                        const float4 v = f4add(o[b], bv);
+                        float4 v = f4add(o[b], bv);
+                        if (accumulate) v = f4add(dst[(size_t)b * C4o], v);      // data gradients: y += (two producers of one activation gradient)
                         dst[(size_t)b * C4o] = v;
                         s1 = f4add(s1, v);
                         s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
@@ -288,6 +289,36 @@ __global__ void winograd4_weight_kernel(const float* __restrict__ w, float* __re
             U[(size_t)(6 * a + b) * total + i] = (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
 }
 
+// U of the ADJOINT convolution (data gradient of a 3x3 / s1 / p1 layer = the same convolution of dy with the filter flipped and its
+// channel roles swapped): U[xi][ci][co] = (G g' G^T)[xi], g'[r][s] = w[co][ci][2 - r][2 - s]; rows = ci, K = co (zero beyond Cout)
+__global__ void winograd4_weight_adjoint_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int rows_pad, int KP) {
+    const int64_t total = (int64_t)rows_pad * KP;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int ci = (int)(i / KP), co = (int)(i - (int64_t)ci * KP);
+    double g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) g[r][s] = (co < Cout && ci < Cin) ? (double)w[(((size_t)co * Cin + ci) * 3 + (2 - r)) * 3 + (2 - s)] : 0.0;
+    const double G[6][3] = {{1.0, 0.0, 0.0},
+                            {8.0 / 65.0, 12.0 / 65.0, 18.0 / 65.0},
+                            {8.0 / 65.0, -12.0 / 65.0, 18.0 / 65.0},
+                            {-81.0 / 130.0, -27.0 / 65.0, -18.0 / 65.0},
+                            {-81.0 / 130.0, 27.0 / 65.0, -18.0 / 65.0},
+                            {0.0, 0.0, 1.0}};
+    double t[6][3];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) t[a][s] = G[a][0] * g[0][s] + G[a][1] * g[1][s] + G[a][2] * g[2][s];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b)
+            U[(size_t)(6 * a + b) * total + i] = (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
+}
+
 int output_tb(int T, int C4o) {
     // tiles per block of the output transform: 256 / C4o tiles are in flight per pass; small maps (19x19 at batch 32: 800 tiles) get one
     // pass per block so that the grid still covers the chip, large ones up to four
@@ -315,6 +346,14 @@ int ssdhip_winograd4_weight(const float* w_oihw, float* U, int Cout, int Cin, in
     SSDHIP_REQUIRE(w_oihw && U && Cout > 0 && Cin > 0 && rows_pad >= Cout && KP >= Cin && KP % 32 == 0, "winograd4_weight: bad arguments");
     const int64_t total = (int64_t)rows_pad * KP;
     hipLaunchKernelGGL(winograd4_weight_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, U, Cout, Cin, rows_pad, KP);
+    SSDHIP_CHECK_LAUNCH();
+    return SSDHIP_OK;
+}
+
+int ssdhip_winograd4_weight_adjoint(const float* w_oihw, float* U, int Cout, int Cin, int rows_pad, int KP, void* stream) {
+    SSDHIP_REQUIRE(w_oihw && U && Cout > 0 && Cin > 0 && rows_pad >= Cin && KP >= Cout && KP % 32 == 0, "winograd4_weight_adjoint: bad arguments");
+    const int64_t total = (int64_t)rows_pad * KP;
+    hipLaunchKernelGGL(winograd4_weight_adjoint_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, U, Cout, Cin, rows_pad, KP);
     SSDHIP_CHECK_LAUNCH();
     return SSDHIP_OK;
 }
@@ -362,8 +401,8 @@ int ssdhip_winograd4_stat_rows(int N, int H, int W, int Cout) {
     return cdiv(T, output_tb(T, Cout / 4));
 }
 
-int ssdhip_winograd4_output(const float* Mo, const float* bias, float* y, float* stats, int N, int H, int W, int Cout, int Tp,
-                            void* stream) {
+int ssdhip_winograd4_output(const float* Mo, const float* bias, float* y, float* stats, int accumulate, int N, int H, int W, int Cout,
+                            int Tp, void* stream) {
     SSDHIP_REQUIRE(Mo && y && Cout > 0, "winograd4_output: bad arguments");
     SSDHIP_REQUIRE(Cout % 4 == 0 && 256 % (Cout / 4) == 0, "winograd4_output: Cout must be 4 * a divisor of 256 (<= 1024)");
     int T, Tp128;
@@ -372,7 +411,7 @@ int ssdhip_winograd4_output(const float* Mo, const float* bias, float* y, float*
     const int TH = (H + 3) / 4, TW = (W + 3) / 4, tb = output_tb(T, Cout / 4);
     hipLaunchKernelGGL(winograd4_output_kernel, dim3(cdiv(T, tb)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const float4*>(Mo), reinterpret_cast<const float4*>(bias), reinterpret_cast<float4*>(y), stats,
-                       H, W, Cout / 4, TH, TW, T, Tp, tb);
+                       H, W, Cout / 4, TH, TW, T, Tp, tb, accumulate);
     SSDHIP_CHECK_LAUNCH();
     return cdiv(T, tb);      // rows of the BN partial table
 }

@@ -362,7 +362,7 @@ class Engine:
                                   kernel='gemm_planes_dma_kernel<%d, 128, 0, 8, 0>' % (tile // 1000),
                                   direct_flops=2.0 * N * h * w * spec.cin * spec.cout * 9,
                                   flops=2.0 * 36 * tp * spec.cin * spec.cout, e0=e0, e1=e1))
-        return _lib.check(L.ssdhip_winograd4_output(_lib.ptr(Mo), _lib.ptr(bias), _lib.ptr(z), _lib.ptr(stats), N, h, w, spec.cout, tp, st),
+        return _lib.check(L.ssdhip_winograd4_output(_lib.ptr(Mo), _lib.ptr(bias), _lib.ptr(z), _lib.ptr(stats), 0, N, h, w, spec.cout, tp, st),
                           f'winograd4_output {spec.name}')
 
     def _conv_winograd(self, spec, x, xs, z, ws, N, h, w, stats):
@@ -838,6 +838,14 @@ class Engine:
                 dg_v, dg_m = max(dg_v, 16 * tp * s.conv.cout), max(dg_m, 16 * tp * s.conv.cin)
         bw['dg_v'] = torch.empty(dg_v, **f) if dg_v else None
         bw['dg_m'] = torch.empty(dg_m, **f) if dg_m else None
+        d4_v = d4_m = 0             # F(4x4) data gradients of detector heads (det_7_1): dy planes V and dx planes M
+        for i in range(self.tail_start, len(self.stages)):
+            s, g = self.stages[i], geo[i]
+            if s.head is not None and self._head_dgrad_wino4(s.head, g['ho'], g['wo']):
+                tp = _rup(N * ((g['ho'] + 3) // 4) * ((g['wo'] + 3) // 4), 128)
+                d4_v, d4_m = max(d4_v, 36 * tp * s.head.co_pad), max(d4_m, 36 * tp * s.head.cin)
+        bw['d4_v'] = torch.empty(d4_v, **f) if d4_v else None
+        bw['d4_m'] = torch.empty(d4_m, **f) if d4_m else None
         b['bwd'] = bw
         return bw
 
@@ -882,6 +890,37 @@ class Engine:
         else:
             fn = self.lib.ssdhip_conv2d_wgrad
         _lib.check(fn(ctypes.byref(p), _lib.stream()), f'wgrad {spec.name}')
+
+    def _head_dgrad_wino4(self, spec, h, w):
+        """Data gradient of a detector head on a >= 16-px map through the F(4x4) passes (the adjoint convolution of dy): det_7_1 of SSD300
+        (19x19, 1024 <- 150 channels: 322 us on the implicit-GEMM gather kernel, 36 of every 144 of its MFMA flops needed here)."""
+        return (self._wino_mode == 'f4' and not self.bf16 and spec.is_head and spec.k == 3 and spec.stride == 1 and spec.pad == 1
+                and spec.cin >= 256 and spec.cin % 4 == 0 and 256 % (spec.cin // 4) == 0 and spec.co_pad % 32 == 0 and min(h, w) >= 16)
+
+    def _head_dgrad_winograd4(self, spec, dy, dx, bw, N, h, w, accumulate):
+        L, st = self.lib, _lib.stream()
+        wt, _ = self._weight(spec)
+        key = (wt.data_ptr(), wt._version, self.m._hip_epoch)
+        rows = _rup(spec.cin, 128)
+        if getattr(spec, 'd4_u', None) is None or spec.d4_u.device != wt.device:
+            spec.d4_u = torch.empty(36 * rows * spec.co_pad, device=wt.device, dtype=torch.float32)
+            spec.d4_key = None
+        if spec.d4_key != key:
+            _lib.check(L.ssdhip_winograd4_weight_adjoint(_lib.ptr(wt), _lib.ptr(spec.d4_u), spec.cout, spec.cin, rows, spec.co_pad, st),
+                       f'winograd4_weight_adjoint {spec.name}')
+            spec.d4_key = key
+        V, Mo = bw['d4_v'], bw['d4_m']
+        tp = _rup(N * ((h + 3) // 4) * ((w + 3) // 4), 128)
+        _lib.check(L.ssdhip_winograd4_input(_lib.ptr(dy), None, None, _lib.ptr(V), N, h, w, spec.co_pad, tp, st), f'winograd4_input (dgrad {spec.name})')
+        p = _lib.ConvParams()
+        p.x, p.w, p.y, p.y_batch_stride = V.data_ptr(), spec.d4_u.data_ptr(), Mo.data_ptr(), tp * spec.cin
+        p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout = 36, 1, tp, spec.co_pad, 1, tp, spec.cin
+        p.R, p.S, p.stride, p.pad, p.KP, p.mode, p.accumulate = 1, 1, 1, 0, spec.co_pad, 0, 0
+        p.tile = 128128
+        p.rows_per_img, p.w_img_stride = tp, rows * spec.co_pad
+        self._plane_gemm(p, tp, spec.co_pad, spec.cin, rows * spec.co_pad, f'winograd4 gemm (dgrad {spec.name})', planes=36)
+        _lib.check(L.ssdhip_winograd4_output(_lib.ptr(Mo), None, _lib.ptr(dx), None, int(accumulate), N, h, w, spec.cin, tp, st),
+                   f'winograd4_output (dgrad {spec.name})')
 
     def _dgrad_wino(self, spec, g):
         """Data gradient of a 3x3/s1/p1 layer = the same convolution of dy with the flipped, transposed filter: it runs through the
@@ -982,7 +1021,10 @@ class Engine:
             if s.head is not None:
                 with fork.side():
                     self._wgrad(s.head, x_act, x_xs, bw['dyh'][i], views, bw, N, g['ho'], g['wo'], g['ho'], g['wo'], None if self.bf16 else b['head_v'].get(i))
-                self._dgrad(s.head, bw['dyh'][i], da, N, g['ho'], g['wo'], g['ho'], g['wo'], accumulate=(i != last))
+                if self._head_dgrad_wino4(s.head, g['ho'], g['wo']) and bw['d4_v'] is not None:
+                    self._head_dgrad_winograd4(s.head, bw['dyh'][i], da, bw, N, g['ho'], g['wo'], accumulate=(i != last))
+                else:
+                    self._dgrad(s.head, bw['dyh'][i], da, N, g['ho'], g['wo'], g['ho'], g['wo'], accumulate=(i != last))
             # BatchNorm(train) + ReLU backward: da -> dz, d gamma, d beta
             bst = self._bn[s.bn_name]
             M = N * g['ho'] * g['wo']

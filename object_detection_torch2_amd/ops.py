@@ -393,6 +393,38 @@ def conv3x3_winograd4(x, w_oihw, bias=None, in_scale=None, in_shift=None, want_s
     _lib.check(lib.ssdhip_conv2d_nhwc(ctypes.byref(p), st), 'winograd4 gemm')
     rows = _lib.check(lib.ssdhip_winograd4_stat_rows(N, H, W, cout), 'winograd4_stat_rows')
     stats = torch.empty(rows, cout, 2, device=dev, dtype=torch.float32) if want_stats else None
-    got = _lib.check(lib.ssdhip_winograd4_output(_lib.ptr(Mo), _lib.ptr(bias), _lib.ptr(z), _lib.ptr(stats), N, H, W, cout, Tp, st), 'winograd4_output')
+    got = _lib.check(lib.ssdhip_winograd4_output(_lib.ptr(Mo), _lib.ptr(bias), _lib.ptr(z), _lib.ptr(stats), 0, N, H, W, cout, Tp, st), 'winograd4_output')
     assert got == rows
     return z, stats
+
+
+def conv3x3_dgrad_winograd4(dy, w_oihw, accumulate_into=None):
+    """Data gradient of a 3x3 / stride 1 / pad 1 convolution through the F(4x4,3x3) passes: the adjoint convolution of dy.
+    dy (N,H,W,KP) with KP = Cout padded to a multiple of 32 (zero channels beyond Cout) -> dx (N,H,W,Cin)."""
+    _lib.require_gpu(dy, w_oihw)
+    lib = _lib.load()
+    N, H, W, KP = dy.shape
+    cout, cin, k, _ = w_oihw.shape
+    if k != 3 or KP < cout or KP % 32 or cin % 4 or 256 % (cin // 4):
+        raise ValueError('conv3x3_dgrad_winograd4: 3x3 kernels, dy rows padded to 32 channels, Cin = 4 * a divisor of 256')
+    T, Tp = ctypes.c_int(), ctypes.c_int()
+    _lib.check(lib.ssdhip_winograd4_tiles(N, H, W, 128, ctypes.byref(T), ctypes.byref(Tp)), 'winograd4_tiles')
+    T, Tp = T.value, Tp.value
+    rows = _rup(cin, 128)
+    dev = dy.device
+    U = torch.empty(36 * rows * KP, device=dev, dtype=torch.float32)
+    V = torch.zeros(36 * Tp * KP, device=dev, dtype=torch.float32)
+    Mo = torch.empty(36 * Tp * cin, device=dev, dtype=torch.float32)
+    dx = accumulate_into if accumulate_into is not None else torch.empty(N, H, W, cin, device=dev, dtype=torch.float32)
+    st = _lib.stream()
+    _lib.check(lib.ssdhip_winograd4_weight_adjoint(_lib.ptr(_lib.f32c(w_oihw)), _lib.ptr(U), cout, cin, rows, KP, st), 'winograd4_weight_adjoint')
+    _lib.check(lib.ssdhip_winograd4_input(_lib.ptr(dy), None, None, _lib.ptr(V), N, H, W, KP, Tp, st), 'winograd4_input')
+    p = _lib.ConvParams()
+    p.x, p.w, p.y, p.y_batch_stride = V.data_ptr(), U.data_ptr(), Mo.data_ptr(), Tp * cin
+    p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout = 36, 1, Tp, KP, 1, Tp, cin
+    p.R, p.S, p.stride, p.pad, p.KP, p.mode, p.accumulate, p.tile = 1, 1, 1, 0, KP, 0, 0, 128128
+    p.rows_per_img, p.w_img_stride = Tp, rows * KP
+    _lib.check(lib.ssdhip_conv2d_nhwc(ctypes.byref(p), st), 'winograd4 gemm (dgrad)')
+    _lib.check(lib.ssdhip_winograd4_output(_lib.ptr(Mo), None, _lib.ptr(dx), None, int(accumulate_into is not None), N, H, W, cin, Tp, st),
+               'winograd4_output (dgrad)')
+    return dx

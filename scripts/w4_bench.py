@@ -54,7 +54,7 @@ for name, N, H, W, cin, cout in SHAPES:
     p.rows_per_img, p.w_img_stride = tp, rows_pad * cin
     t_in = timed(lambda: _lib.check(lib.ssdhip_winograd4_input(_lib.ptr(x), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(V), N, H, W, cin, tp, st), 'in'))
     t_g = timed(lambda: _lib.check(lib.ssdhip_conv2d_nhwc(ctypes.byref(p), st), 'gemm'))
-    t_out = timed(lambda: _lib.check(lib.ssdhip_winograd4_output(_lib.ptr(M), _lib.ptr(b), _lib.ptr(z), _lib.ptr(stats), N, H, W, cout, tp, st), 'out'))
+    t_out = timed(lambda: _lib.check(lib.ssdhip_winograd4_output(_lib.ptr(M), _lib.ptr(b), _lib.ptr(z), _lib.ptr(stats), 0, N, H, W, cout, tp, st), 'out'))
     gf = 2.0 * 36 * tp * cin * cout / 1e9
     mb_in = (x.numel() + V.numel()) * 4 / 1e6
     mb_out = (M.numel() + z.numel()) * 4 / 1e6

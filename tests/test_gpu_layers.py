@@ -316,6 +316,34 @@ def test_conv3x3_winograd4(case):
     print(f'winograd4 {case}: max err / max |out| vs fp64 {e4:.2e}; F(2x2) {rel_err(z3.permute(0, 3, 1, 2).cpu().double(), ref64):.2e}; torch fp32 {rel_err(ref.double(), ref64):.2e}')
 
 
+@pytest.mark.parametrize('case', [(2, 19, 19, 256, 150), (1, 16, 16, 512, 100), (3, 10, 13, 256, 64)])
+def test_dgrad_winograd4(case):
+    """Data gradient of a detector-head-like 3x3/s1/p1 layer through the F(4x4) passes (adjoint convolution of the channel-padded dy) vs
+    autograd; then accumulated onto an existing gradient (two producers of one activation gradient)."""
+    from object_detection_torch2_amd import ops
+    N, H, W, cin, cout = case
+    a = rnd(N, cin, H, W, seed=241).requires_grad_(True)
+    w = rnd(cout, cin, 3, 3, seed=242, scale=0.05)
+    y = F.conv2d(a, w, None, padding=1)
+    dy = rnd(*y.shape, seed=243)
+    y.backward(dy)
+    cpad = (cout + 31) // 32 * 32
+    dyp = ops.to_nhwc(dy.to(DEV), pad_to=cpad)
+    dx = ops.conv3x3_dgrad_winograd4(dyp, w.to(DEV))
+    ref = a.grad
+    assert rel_err(dx.permute(0, 3, 1, 2).cpu(), ref) < 1e-4
+    a64 = a.detach().double().requires_grad_(True)
+    F.conv2d(a64, w.double(), None, padding=1).backward(dy.double())
+    e4 = rel_err(dx.permute(0, 3, 1, 2).cpu().double(), a64.grad)
+    assert e4 < 1e-5, e4
+    base = rnd(N, H, W, cin, seed=244).to(DEV)
+    acc = ops.conv3x3_dgrad_winograd4(dyp, w.to(DEV), accumulate_into=base.clone())
+    assert torch.equal(acc, base + dx)              # y += result: one fp32 add per element, same products
+    dx2 = ops.conv2d_dgrad(dyp, w.to(DEV), (H, W), pad=1)
+    assert rel_err(dx.cpu(), dx2.cpu()) < 1e-5           # agrees with the implicit-GEMM gather kernel
+    print(f'dgrad winograd4 {case}: max err / max |dx| vs fp64 {e4:.2e}; gather kernel {rel_err(dx2.permute(0, 3, 1, 2).cpu().double(), a64.grad):.2e}')
+
+
 # (N, H, W, Cin, Cout): odd / even maps, ragged last tile block (T % 64 != 0), one and several channel tiles, short and long K
 WINO_FUSED_CASES = [(2, 19, 19, 64, 64), (1, 38, 38, 64, 128), (3, 9, 11, 32, 64), (2, 30, 30, 128, 256), (1, 16, 12, 512, 192),
                     (5, 11, 13, 48, 64), (1, 150, 150, 32, 64)]
