@@ -315,7 +315,7 @@ def main():
         ach = a['flops'] / (a['ms'] * 1e-3) / 1e12
         traffic = None       # HBM-side bytes per launch from the committed PMC passes (scripts/collect_pmc.sh + pmc_summary.py)
         try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_summary.json')))
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r03_pmc_summary.json')))
             traffic = round(pmc[name]['hbm_bytes_per_launch'])
         except (OSError, KeyError, ValueError):
             pass
@@ -418,7 +418,12 @@ def main():
                     config=dict(workload=f'SSD300 training batch={B}/GPU, fp32, IoU-match thresh=0.25, hard-neg 3:1, Adam '
                                          '(BASELINE configs[2]' + (f'; data-parallel, {"RCCL" if dist.get_backend() == "nccl" else dist.get_backend()} grad all-reduce)' if world > 1 else ')'),
                                 global_batch=world * B, image='300x300x3', priors=8732, classes=21, parallelism=f'dp{world}',
-                                bn='train-mode batch statistics (reference never calls eval())', backbone='frozen VGG16-bn'),
+                                bn='train-mode batch statistics (reference never calls eval())', backbone='frozen VGG16-bn',
+                                conv_algorithms=('fp32 MFMA throughout; 3x3/s1/p1 layers: fused Winograd F(2x2,3x3) (conv_1_2 .. conv_3_1), three-pass '
+                                                 'Winograd F(4x4,3x3) (conv_3_2 .. conv_6_1, heads on >= 16-px maps: forward, weight and data gradients)'
+                                                 if eng._wino_mode == 'f4' else
+                                                 'fp32 MFMA throughout; 3x3/s1/p1 layers: Winograd F(2x2,3x3) everywhere (SSD_WINOGRAD=f2)')
+                                                 if args.dtype == 'fp32' else 'see precision'),
                     conv_flop_roofline_frac=round(value / world * (gf_train if args.mode == 'train' else gf_fwd)
                                                   / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
                     mean_loss=round(final_loss, 4), ranks=(dist.get_world_size() if world > 1 else 1))

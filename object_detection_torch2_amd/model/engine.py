@@ -119,6 +119,7 @@ class Engine:
         self._wino_mode = os.environ.get('SSD_WINOGRAD', 'f4')
         if self._wino_mode not in ('f2', 'f4'):
             raise ValueError(f"SSD_WINOGRAD must be 'f2' or 'f4', got {self._wino_mode!r}")
+        self._w4_min_cin = int(os.environ.get('SSD_W4_MIN_CIN', '256'))      # A/B: 128 also routes conv_3_1 (K = 128) to the F(4x4) passes
         self._cus = None       # compute units of the device (first forward): the persistent backbone grids take 7/8 of them beside the tail
         self._wf_blocks_env = os.environ.get('SSD_WF_BLOCKS')
         self._wf_blocks = int(self._wf_blocks_env) if self._wf_blocks_env is not None else 0
@@ -310,7 +311,7 @@ class Engine:
         first_tail = 0 < self.tail_start < len(self.stages) and c is self.stages[self.tail_start].conv
         return (self._wino_mode == 'f4' and (sizing or not self.bf16) and (c.frozen or first_tail) and not c.is_head
                 and c.k == 3 and c.stride == 1 and c.pad == 1
-                and c.cin >= 256 and c.cin % 32 == 0 and c.cout % 4 == 0 and 256 % (c.cout // 4) == 0
+                and c.cin >= self._w4_min_cin and c.cin % 32 == 0 and c.cout % 4 == 0 and 256 % (c.cout // 4) == 0
                 and 8 <= min(g['hi'], g['wi']) and max(g['hi'], g['wi']) <= 80)
 
     def _wino4_plan(self, c, g, N):

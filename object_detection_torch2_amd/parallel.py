@@ -54,8 +54,9 @@ class GradAllReduce:
     The 1/world factor is applied by the optimizer (FusedAdam grad_scale) so no extra pass over the buffer is needed;
     with average=True the buffer itself is scaled (stock torch.optim users)."""
 
-    def __init__(self, group=None, n_buckets=2, average=False):
+    def __init__(self, group=None, n_buckets=2, average=False, force=False):
         self.group, self.n_buckets, self.average = group, max(1, n_buckets), average
+        self.force = force         # issue the collectives even in a one-rank group (RCCL rehearsal on a one-GPU box: tests/test_gpu_dist.py)
         self._works, self._done_from, self._extra = [], None, []
 
     def bucket_ranges(self, n, lo=0):
@@ -64,7 +65,7 @@ class GradAllReduce:
         return [(a, min(n, a + step)) for a in range(lo, n, step)]
 
     def _active(self):
-        return dist.is_initialized() and dist.get_world_size(self.group) > 1
+        return dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.force)
 
     def start(self, flat, lo, hi):
         if not self._active():

@@ -19,6 +19,16 @@ def test_two_rank_data_parallel_step_on_one_gpu():
     assert 'weights identical across ranks after step: True' in r.stdout
 
 
+def test_rccl_one_rank_group_carries_the_gradient_allreduce():
+    """RCCL itself on this box's one GPU (scripts/rccl_world1_check.py): a one-rank `nccl` group runs the step's real all-reduce pattern
+    (early bucket next to the last weight gradient, asynchronous handles, RCCL's stream against the engine's three) over three
+    unsynchronised steps; with one rank the sum is the identity, so everything must be bit-identical to the steps without the hook."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'rccl_world1_check.py')], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert 'backend nccl' in r.stdout and 'identical to the unhooked steps: True' in r.stdout
+
+
 def test_two_rank_classification_step_on_one_gpu():
     """`train.py --purpose classification` under data parallelism: the classifier stack's gradients (fc1: 411 MB) travel
     through the asynchronous hook like the feature gradients, per-rank dropout seeds, identical weights after the step."""

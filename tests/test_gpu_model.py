@@ -499,3 +499,36 @@ def test_fused_adam_follows_replaced_state_and_bumps_versions(env):
     assert third == la[2]                                                             # == the uninterrupted run's third step
     for (k, x), (_, y) in zip(a.state_dict().items(), c.state_dict().items()):
         assert torch.equal(x, y), k
+
+
+def test_winograd_f2_switch_runs_the_same_network(env, monkeypatch):
+    """SSD_WINOGRAD=f2 keeps every 3x3 layer on the F(2x2) kernels (the tighter-rounding form: per layer 5e-7 of the output scale against
+    fp64 instead of 1.5-2.8e-6 for F(4x4), tests/test_gpu_layers.py).  Both modes are the same network: forward within the noise the
+    golden tests allow either of them, same loss to 1e-4, tail gradients in the same direction."""
+    O, synth = env['O'], env['synth']
+    ims = torch.from_numpy(synth.images(40, 4)).to(DEV)
+    tg = torch.from_numpy(synth.targets(50, 4, g_max=8)).to(DEV)
+    res = {}
+    for mode in ('f4', 'f2'):
+        monkeypatch.setenv('SSD_WINOGRAD', mode)
+        net = make_net(env)
+        df = net.default_bboxes.to(DEV)
+        out = net(ims)
+        assert net._engine()._wino_mode == mode
+        loss = net.loss(out, tg, df)
+        loss.backward()
+        res[mode] = (out.detach().clone(), loss.item(), {k: p.grad.detach().clone() for k, p in net.named_train_params()})
+    monkeypatch.setenv('SSD_WINOGRAD', 'f3')
+    with pytest.raises(ValueError):
+        make_net(env)(ims)
+    o4, l4, g4 = res['f4']
+    o2, l2, g2 = res['f2']
+    assert not torch.equal(o4, o2)                                   # two different algorithms really ran
+    assert (o4 - o2).abs()[:, :8692].max().item() < 1e-3             # measured 2e-4 (large maps); the 3x3 / 1x1 maps of a batch of 4 amplify more
+    assert (o4 - o2).abs().max().item() < 4e-3
+    assert abs(l4 - l2) < 1e-4 * max(1.0, abs(l2))
+    for k in g2:
+        if 'features.conv' in k and k.endswith('.bias'):
+            continue
+        a, b = g4[k].double().flatten(), g2[k].double().flatten()
+        assert torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30) > 0.998, k
