@@ -279,6 +279,14 @@ int64_t ssdhip_wino_fused_geo_bytes(int N, int H, int W);
 int ssdhip_wino_fused_geo(int N, int H, int W, void* geo, void* stream);
 int ssdhip_wino_fused_conv(const float* x, const float* upk, const float* bias, const float* in_scale, const float* in_shift, float* z,
                            float* stats, const void* geo, int N, int H, int W, int Cin, int Cout, int max_blocks, void* stream);
+/* the same layer when a 2x2 / stride 2 / pad 0 nn.MaxPool2d follows (model/vgg16.py:36; even H, W): instead of z (N,H,W,Cout) the
+ * kernel stores, per pooling window, max z and min z -- zmax, zmin (N,H/2,W/2,Cout) -- and ssdhip_bn_relu_select turns them into the
+ * pooled activation max-pool(relu(bn(z))) exactly (relu(bn(.)) is monotonic in z); BN partial sums still cover every z */
+int ssdhip_wino_fused_conv_pool(const float* x, const float* upk, const float* bias, const float* in_scale, const float* in_shift,
+                                float* zmax, float* zmin, float* stats, const void* geo, int N, int H, int W, int Cin, int Cout,
+                                int max_blocks, void* stream);
+int ssdhip_bn_relu_select(const float* zmax, const float* zmin, const float* scale, const float* shift, float* y, int64_t pixels, int C,
+                          void* stream);
 
 /* ---- BASELINE configs[3] / [4] (bf16 forward / backward with fp32 master weights), backbone forward: the 3x3/s1/p1 layers of
  * model/vgg16.py:33 on bf16 activations kept in HBM, v_mfma_f32_32x32x16_bf16 with fp32 accumulation, fed by LDS-DMA from an image

@@ -119,6 +119,24 @@ __global__ __launch_bounds__(256) void bn_stats_stage2(const double* __restrict_
     }
 }
 
+// pooled activation from the window maxima / minima the producing convolution stored (ssdhip_wino_fused_conv_pool):
+// max over a window of relu(z * scale + shift) = relu(bn(max z)) where scale >= 0, relu(bn(min z)) where scale < 0 -- the same fma and
+// max on the same element the pool pass would have picked, so the result is the pool pass's bit for bit
+__global__ __launch_bounds__(256) void bn_relu_select_kernel(const float4* __restrict__ zmax, const float4* __restrict__ zmin,
+                                                             const float4* __restrict__ scale, const float4* __restrict__ shift,
+                                                             float4* __restrict__ y, int C4, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = (int)(i % C4);
+    const float4 sc = scale[c4], sh = shift[c4], a = zmax[i], b = zmin[i];
+    float4 v;
+    v.x = fmaxf(fmaf(sc.x >= 0.f ? a.x : b.x, sc.x, sh.x), 0.f);
+    v.y = fmaxf(fmaf(sc.y >= 0.f ? a.y : b.y, sc.y, sh.y), 0.f);
+    v.z = fmaxf(fmaf(sc.z >= 0.f ? a.z : b.z, sc.z, sh.z), 0.f);
+    v.w = fmaxf(fmaf(sc.w >= 0.f ? a.w : b.w, sc.w, sh.w), 0.f);
+    y[i] = v;
+}
+
 __global__ void bn_fold_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
                                     const float* __restrict__ rv, float eps, int C, float* __restrict__ scale,
                                     float* __restrict__ shift) {
@@ -332,6 +350,17 @@ int ssdhip_bn_finalize(const float* partial, int MB, int C, int64_t count, const
     SSDHIP_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_stats_stage2, dim3(cdiv(C, 32)), dim3(256), 0, st, ws, split, C, (double)count, gamma, beta, running_mean,
                        running_var, momentum, eps, scale, shift, save_mean, save_invstd);
+    SSDHIP_CHECK_LAUNCH();
+    return SSDHIP_OK;
+}
+
+int ssdhip_bn_relu_select(const float* zmax, const float* zmin, const float* scale, const float* shift, float* y, int64_t pixels, int C,
+                          void* stream) {
+    SSDHIP_REQUIRE(zmax && zmin && scale && shift && y && pixels > 0 && C > 0 && C % 4 == 0, "bn_relu_select: bad arguments (C % 4 == 0)");
+    const int64_t total = pixels * (C / 4);
+    hipLaunchKernelGGL(bn_relu_select_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(zmax),
+                       reinterpret_cast<const float4*>(zmin), reinterpret_cast<const float4*>(scale), reinterpret_cast<const float4*>(shift),
+                       reinterpret_cast<float4*>(y), C / 4, total);
     SSDHIP_CHECK_LAUNCH();
     return SSDHIP_OK;
 }

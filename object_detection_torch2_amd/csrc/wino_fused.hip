@@ -80,6 +80,8 @@ struct WfArgs {
     const int* geo;
     float* z;
     float* stats;
+    float* zmax;      // 2x2 max-pool fusion (8-wave kernel): per tile = pooling window the maximum and the minimum of z instead of z itself
+    float* zmin;
     int H, W, C, Cout, KT, NB, MB;
     unsigned x_bytes;
     int band;         // 1 = an XCD walks a contiguous band of tile blocks (see the kernel), 0 = tile blocks dealt round-robin over the XCDs
@@ -755,6 +757,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     y[cg][aa][1] = ((r[aa][1] - r[aa][2]) - r[aa][3]) + bv;
                 }
             }
+            if (a.zmax != nullptr) {
+                // a 2x2 / stride 2 / pad 0 max-pool follows (even H, W: a tile IS a pooling window and the tile index the pooled pixel):
+                // store max and min of the window -- relu(bn(.)) is monotonic in z, rising for scale >= 0 and falling below, so
+                // max over the window of relu(bn(z)) = relu(bn(max z)) resp. relu(bn(min z)) exactly (ssdhip_bn_relu_select).  z itself
+                // is never written: a quarter of the store traffic twice instead of once in full, and the pool pass reads 2/4 instead of 4/4.
+                if ((ent.x >> 8) & 1) {
+                    float* pm = a.zmax + ((size_t)mb * WF_TILES + i) * a.Cout + co0;
+                    float* pn = a.zmin + ((size_t)mb * WF_TILES + i) * a.Cout + co0;
+                    float mx[2], mn[2];
+#pragma unroll
+                    for (int cg = 0; cg < 2; ++cg) {
+                        mx[cg] = fmaxf(fmaxf(y[cg][0][0], y[cg][0][1]), fmaxf(y[cg][1][0], y[cg][1][1]));
+                        mn[cg] = fminf(fminf(y[cg][0][0], y[cg][0][1]), fminf(y[cg][1][0], y[cg][1][1]));
+#pragma unroll
+                        for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                            for (int bb = 0; bb < 2; ++bb) { s1[cg] += y[cg][aa][bb]; s2[cg] += y[cg][aa][bb] * y[cg][aa][bb]; }
+                    }
+                    if (!(ABL & 8)) {
+                        *reinterpret_cast<float2*>(pm) = make_float2(mx[0], mx[1]);
+                        *reinterpret_cast<float2*>(pn) = make_float2(mn[0], mn[1]);
+                    }
+                }
+                continue;
+            }
             float* zp = a.z + (size_t)ent.y * a.Cout + co0;
 #pragma unroll
             for (int aa = 0; aa < 2; ++aa) {
@@ -846,9 +873,10 @@ int ssdhip_wino_fused_geo(int N, int H, int W, void* geo, void* stream) {
     return SSDHIP_OK;
 }
 
-int ssdhip_wino_fused_conv(const float* x, const float* upk, const float* bias, const float* in_scale, const float* in_shift, float* z,
-                           float* stats, const void* geo, int N, int H, int W, int Cin, int Cout, int max_blocks, void* stream) {
-    SSDHIP_REQUIRE(x && upk && z && geo && N > 0 && H > 0 && W > 0 && max_blocks >= 0, "wino_fused_conv: bad arguments");
+static int wino_fused_launch(const float* x, const float* upk, const float* bias, const float* in_scale, const float* in_shift, float* z,
+                             float* zmax, float* zmin, float* stats, const void* geo, int N, int H, int W, int Cin, int Cout, int max_blocks,
+                             void* stream) {
+    SSDHIP_REQUIRE(x && upk && (z || (zmax && zmin)) && geo && N > 0 && H > 0 && W > 0 && max_blocks >= 0, "wino_fused_conv: bad arguments");
     SSDHIP_REQUIRE(Cin >= 32 && Cin % 16 == 0 && Cin <= WF_MAXC && Cout > 0 && Cout % WF_COUT == 0,
                    "wino_fused_conv: Cin must be a multiple of 16 in 32..512 and Cout a multiple of 64");
     SSDHIP_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "wino_fused_conv: in_scale and in_shift go together");
@@ -874,7 +902,7 @@ int ssdhip_wino_fused_conv(const float* x, const float* upk, const float* bias, 
         attr.mark(dev);
     }
     WfArgs a;
-    a.x = x; a.upk = upk; a.bias = bias; a.scale = in_scale; a.shift = in_shift; a.z = z; a.stats = stats;
+    a.x = x; a.upk = upk; a.bias = bias; a.scale = in_scale; a.shift = in_shift; a.z = z; a.stats = stats; a.zmax = zmax; a.zmin = zmin;
     a.geo = reinterpret_cast<const int*>(geo);
     a.H = H; a.W = W; a.C = Cin; a.Cout = Cout;
     a.KT = Cin / WF_BK; a.NB = Cout / WF_COUT;
@@ -925,6 +953,19 @@ int ssdhip_wino_fused_conv(const float* x, const float* upk, const float* bias, 
     else hipLaunchKernelGGL(wino_fused8_kernel<false>, grid, dim3(512), WF_LDS, st, a);
     SSDHIP_CHECK_LAUNCH();
     return a.MB;      // rows of the BatchNorm partial table
+}
+
+int ssdhip_wino_fused_conv(const float* x, const float* upk, const float* bias, const float* in_scale, const float* in_shift, float* z,
+                           float* stats, const void* geo, int N, int H, int W, int Cin, int Cout, int max_blocks, void* stream) {
+    SSDHIP_REQUIRE(z, "wino_fused_conv: bad arguments");
+    return wino_fused_launch(x, upk, bias, in_scale, in_shift, z, nullptr, nullptr, stats, geo, N, H, W, Cin, Cout, max_blocks, stream);
+}
+
+int ssdhip_wino_fused_conv_pool(const float* x, const float* upk, const float* bias, const float* in_scale, const float* in_shift,
+                                float* zmax, float* zmin, float* stats, const void* geo, int N, int H, int W, int Cin, int Cout,
+                                int max_blocks, void* stream) {
+    SSDHIP_REQUIRE(zmax && zmin && H % 2 == 0 && W % 2 == 0, "wino_fused_conv_pool: even H and W (a Winograd tile must be a pooling window)");
+    return wino_fused_launch(x, upk, bias, in_scale, in_shift, nullptr, zmax, zmin, stats, geo, N, H, W, Cin, Cout, max_blocks, stream);
 }
 
 }  // extern "C"

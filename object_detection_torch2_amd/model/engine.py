@@ -119,6 +119,7 @@ class Engine:
         self._wino_mode = os.environ.get('SSD_WINOGRAD', 'f4')
         if self._wino_mode not in ('f2', 'f4'):
             raise ValueError(f"SSD_WINOGRAD must be 'f2' or 'f4', got {self._wino_mode!r}")
+        self._pool_fuse = os.environ.get('SSD_NO_POOL_FUSE') != '1'      # A/B: conv + 2x2 max-pool without materialising z (conv_1_2, conv_2_2)
         self._w4_min_cin = int(os.environ.get('SSD_W4_MIN_CIN', '256'))      # A/B: 128 also routes conv_3_1 (K = 128) to the F(4x4) passes
         self._cus = None       # compute units of the device (first forward): the persistent backbone grids take 7/8 of them beside the tail
         self._wf_blocks_env = os.environ.get('SSD_WF_BLOCKS')
@@ -626,6 +627,7 @@ class Engine:
                 # z of a patch layer is bf16 when only the next layer's apply pass reads it (no head, no fp32 consumer)
                 z_bf16 = (patch and nxt_patch and s.head is None and i + 1 < self.tail_start
                           and self._z_bf16)
+                pool_fused = False
                 if patch:
                     w1, b1 = self._weight(c)
                     key = (w1.data_ptr(), w1._version, self.m._hip_epoch if not c.frozen else 0)
@@ -664,12 +666,28 @@ class Engine:
                     if self.prof is not None:
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record()
-                    rows = _lib.check(self.lib.ssdhip_wino_fused_conv(_lib.ptr(cur), _lib.ptr(c.wf_img), _lib.ptr(b1) if b1 is not None else None,
-                                                                      _lib.ptr(cur_xs[0]) if cur_xs is not None else None,
-                                                                      _lib.ptr(cur_xs[1]) if cur_xs is not None else None, _lib.ptr(z),
-                                                                      _lib.ptr(ws['partial']) if training else None,
-                                                                      _lib.ptr(self._wf_geo(b, N, g['hi'], g['wi'], dev)), N, g['hi'], g['wi'],
-                                                                      c.cin, c.cout, self._wf_blocks, st), f'conv2d {c.name}')
+                    # frozen layer in front of a 2x2 / pad 0 max-pool on an even map (conv_1_2, conv_2_2): the kernel stores the window
+                    # maxima and minima of z instead of z, the pool pass becomes a select over a quarter-size pair (bit-identical result)
+                    pool_fused = (self._pool_fuse and c.frozen and s.pool_pad == 0 and s.head is None and not nxt_patch
+                                  and g['ho'] % 2 == 0 and g['wo'] % 2 == 0)
+                    if pool_fused:
+                        zmm = b.setdefault('zmm', {}).get(i)
+                        if zmm is None:
+                            zmm = torch.empty(2, N, g['ha'], g['wa'], c.cout, device=dev, dtype=torch.float32)
+                            b['zmm'][i] = zmm
+                        rows = _lib.check(self.lib.ssdhip_wino_fused_conv_pool(_lib.ptr(cur), _lib.ptr(c.wf_img), _lib.ptr(b1) if b1 is not None else None,
+                                                                               _lib.ptr(cur_xs[0]) if cur_xs is not None else None,
+                                                                               _lib.ptr(cur_xs[1]) if cur_xs is not None else None,
+                                                                               _lib.ptr(zmm[0]), _lib.ptr(zmm[1]), _lib.ptr(ws['partial']) if training else None,
+                                                                               _lib.ptr(self._wf_geo(b, N, g['hi'], g['wi'], dev)), N, g['hi'], g['wi'],
+                                                                               c.cin, c.cout, self._wf_blocks, st), f'conv2d {c.name}')
+                    else:
+                        rows = _lib.check(self.lib.ssdhip_wino_fused_conv(_lib.ptr(cur), _lib.ptr(c.wf_img), _lib.ptr(b1) if b1 is not None else None,
+                                                                          _lib.ptr(cur_xs[0]) if cur_xs is not None else None,
+                                                                          _lib.ptr(cur_xs[1]) if cur_xs is not None else None, _lib.ptr(z),
+                                                                          _lib.ptr(ws['partial']) if training else None,
+                                                                          _lib.ptr(self._wf_geo(b, N, g['hi'], g['wi'], dev)), N, g['hi'], g['wi'],
+                                                                          c.cin, c.cout, self._wf_blocks, st), f'conv2d {c.name}')
                     if self.prof is not None:
                         e1.record()
                         tiles = N * ((g['hi'] + 1) // 2) * ((g['wi'] + 1) // 2)
@@ -739,6 +757,12 @@ class Engine:
                                                                N, g['ho'], g['wo'], c.cout, int(s.pool_pad is not None), s.pool_pad or 0, st),
                                f'bn_relu_to_bf16 after {c.name}')
                     cur, cur_xs = abf, None
+                elif pool_fused:
+                    pooled = b['pooled'][i]
+                    zmm = b['zmm'][i]
+                    _lib.check(self.lib.ssdhip_bn_relu_select(_lib.ptr(zmm[0]), _lib.ptr(zmm[1]), _lib.ptr(bst['scale']), _lib.ptr(bst['shift']),
+                                                              _lib.ptr(pooled), N * g['ha'] * g['wa'], c.cout, st), f'pool (select) after {c.name}')
+                    cur, cur_xs = pooled, None
                 elif s.pool_pad is not None:
                     pooled = b['pooled'][i]
                     _lib.check(self.lib.ssdhip_bn_relu_pool(_lib.ptr(z), _lib.ptr(bst['scale']), _lib.ptr(bst['shift']), _lib.ptr(pooled),

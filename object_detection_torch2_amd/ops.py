@@ -155,6 +155,38 @@ def wino_fused_conv(x, w_oihw, bias=None, in_scale=None, in_shift=None, want_sta
     return z, stats
 
 
+def wino_fused_conv_pool(x, w_oihw, bias=None, in_scale=None, in_shift=None, want_stats=False, upk=None, max_blocks=0):
+    """The fused Winograd convolution when a 2x2 / stride 2 max-pool follows: returns (zmax, zmin (N,H/2,W/2,Cout), stats or None)."""
+    _lib.require_gpu(x, w_oihw)
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    cout, cin = w_oihw.shape[0], w_oihw.shape[1]
+    if cin != C or H % 2 or W % 2:
+        raise ValueError('wino_fused_conv_pool: channel mismatch or odd map size')
+    if upk is None:
+        upk = wino_fused_pack(w_oihw)
+    zmax = torch.empty(N, H // 2, W // 2, cout, device=x.device, dtype=torch.float32)
+    zmin = torch.empty_like(zmax)
+    stats = torch.empty(_lib.check(lib.ssdhip_wino_fused_stat_rows(N, H, W), 'wino_fused_stat_rows'), cout, 2, device=x.device,
+                        dtype=torch.float32) if want_stats else None
+    _lib.check(lib.ssdhip_wino_fused_conv_pool(_lib.ptr(x), _lib.ptr(upk), _lib.ptr(bias) if bias is not None else None,
+                                               _lib.ptr(in_scale) if in_scale is not None else None,
+                                               _lib.ptr(in_shift) if in_shift is not None else None, _lib.ptr(zmax), _lib.ptr(zmin),
+                                               _lib.ptr(stats) if stats is not None else None, _lib.ptr(wino_fused_geo(N, H, W, x.device)),
+                                               N, H, W, C, cout, max_blocks, _lib.stream()), 'wino_fused_conv_pool')
+    return zmax, zmin, stats
+
+
+def bn_relu_select(zmax, zmin, scale, shift):
+    """max-pool(relu(bn(z))) from the window maxima / minima of z (see wino_fused_conv_pool)."""
+    _lib.require_gpu(zmax, zmin, scale, shift)
+    y = torch.empty_like(zmax)
+    C = zmax.shape[-1]
+    _lib.check(_lib.load().ssdhip_bn_relu_select(_lib.ptr(zmax), _lib.ptr(zmin), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(y), zmax.numel() // C, C,
+                                                 _lib.stream()), 'bn_relu_select')
+    return y
+
+
 def conv_bf16_pack(w_oihw):
     """OIHW fp32 (Cout % 64 == 0, Cin % 32 == 0, 3, 3) -> the bf16 patch convolution's weight images (uint8 tensor)."""
     _lib.require_gpu(w_oihw)

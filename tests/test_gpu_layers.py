@@ -377,6 +377,34 @@ def test_conv3x3_winograd_fused(case):
         assert rel_err(z.cpu(), z3.cpu()) < 2e-6
 
 
+@pytest.mark.parametrize('case', [(2, 20, 24, 64, 64), (1, 38, 38, 64, 128), (3, 10, 12, 32, 64), (1, 150, 150, 32, 64)])
+def test_conv3x3_winograd_fused_with_pool(case):
+    """The fused Winograd convolution in front of a 2x2 max-pool stores window max / min of z instead of z; ssdhip_bn_relu_select turns them
+    into the pooled activation.  Must be BIT-identical to the two-pass form (same conv kernel writing z, then ssdhip_bn_relu_pool), for
+    positive, negative and zero BatchNorm scales, and leave the same BatchNorm partial sums."""
+    from object_detection_torch2_amd import ops
+    N, H, W, cin, cout = case
+    zprev = rnd(N, cin, H, W, seed=331)
+    scale, shift = rnd(cin, seed=332), rnd(cin, seed=333) + 0.5
+    w = rnd(cout, cin, 3, 3, seed=334, scale=(2.0 / (cin * 9)) ** 0.5)
+    b = rnd(cout, seed=335)
+    x = ops.to_nhwc(zprev.to(DEV))
+    z, st = ops.wino_fused_conv(x, w.to(DEV), b.to(DEV), in_scale=scale.to(DEV), in_shift=shift.to(DEV), want_stats=True)
+    zmax, zmin, st2 = ops.wino_fused_conv_pool(x, w.to(DEV), b.to(DEV), in_scale=scale.to(DEV), in_shift=shift.to(DEV), want_stats=True)
+    assert torch.equal(st, st2)
+    zz = z.view(N, H // 2, 2, W // 2, 2, cout)
+    assert torch.equal(zmax, zz.amax(dim=(2, 4))) and torch.equal(zmin, zz.amin(dim=(2, 4)))
+    sc2 = rnd(cout, seed=336)                      # both signs
+    sc2[::7] = 0.0
+    sh2 = rnd(cout, seed=337) * 0.3
+    want = ops.bn_relu_pool(z, sc2.to(DEV), sh2.to(DEV), pool=True, pool_pad=0)
+    got = ops.bn_relu_select(zmax, zmin, sc2.to(DEV), sh2.to(DEV))
+    assert torch.equal(got, want)
+    ref = F.max_pool2d(F.relu(F.conv2d(F.relu(zprev * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)), w, b, padding=1) * sc2.view(1, -1, 1, 1)
+                              + sh2.view(1, -1, 1, 1)), 2)
+    assert rel_err(got.permute(0, 3, 1, 2).cpu(), ref) < 1e-4
+
+
 # (N, H, W, Cin, Cout): conv_6_1-like and detector-head-like (Cout padded 150 -> 160, 100 -> 128), odd / even maps
 WINO_WGRAD_CASES = [(2, 19, 19, 64, 128), (2, 10, 10, 128, 150), (3, 7, 9, 64, 100), (1, 38, 38, 64, 100)]
 

@@ -1,4 +1,5 @@
 """Per-stage activation error of the HIP forward and of torch fp32, both vs an fp64 forward; ReLU mask flips."""
+import os; os.environ.setdefault('SSD_NO_POOL_FUSE', '1')      # this tool reads every stage's z: keep conv_1_2 / conv_2_2 materialising it
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, torch.nn.functional as F
