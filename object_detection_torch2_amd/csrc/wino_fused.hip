@@ -498,7 +498,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifndef WF8_MIDP
 #define WF8_MIDP 1      // plane slot of the mid-step barrier + raw-tile refill (A/B: -DWF8_MIDP=2 / 3)
 #endif
-template <bool XFORM, int ABL = 0>       // ABL: timing-only ablations (probe builds; wrong results): 1 no raw-tile DMA, 2 no weight DMA, 4 no transform, 8 no stores
+template <bool XFORM, int ABL = 0, bool POOL = false>       // ABL: timing-only ablations (probe builds; wrong results): 1 no raw-tile DMA, 2 no weight DMA, 4 no transform, 8 no stores; POOL: store window max / min instead of z
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_fused8_kernel(WfArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     y[cg][aa][1] = ((r[aa][1] - r[aa][2]) - r[aa][3]) + bv;
                 }
             }
-            if (a.zmax != nullptr) {
+            if (POOL) {
                 // a 2x2 / stride 2 / pad 0 max-pool follows (even H, W: a tile IS a pooling window and the tile index the pooled pixel):
                 // store max and min of the window -- relu(bn(.)) is monotonic in z, rising for scale >= 0 and falling below, so
                 // max over the window of relu(bn(z)) = relu(bn(max z)) resp. relu(bn(min z)) exactly (ssdhip_bn_relu_select).  z itself
@@ -890,7 +890,9 @@ static int wino_fused_launch(const float* x, const float* upk, const float* bias
     static DeviceOnce attr;
     if (const int dev = attr.pending(); dev != DeviceOnce::kDone) {
         bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) == hipSuccess &&
-                  hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) == hipSuccess;
+                  hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) == hipSuccess &&
+                  hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused8_kernel<true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) == hipSuccess &&
+                  hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused8_kernel<false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) == hipSuccess;
 #ifdef SSDHIP_PROBES
         ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) == hipSuccess &&
              hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) == hipSuccess;
@@ -949,7 +951,10 @@ static int wino_fused_launch(const float* x, const float* upk, const float* bias
         return a.MB;
     }
 #endif
-    if (in_scale) hipLaunchKernelGGL(wino_fused8_kernel<true>, grid, dim3(512), WF_LDS, st, a);
+    if (zmax != nullptr) {
+        if (in_scale) hipLaunchKernelGGL((wino_fused8_kernel<true, 0, true>), grid, dim3(512), WF_LDS, st, a);
+        else hipLaunchKernelGGL((wino_fused8_kernel<false, 0, true>), grid, dim3(512), WF_LDS, st, a);
+    } else if (in_scale) hipLaunchKernelGGL(wino_fused8_kernel<true>, grid, dim3(512), WF_LDS, st, a);
     else hipLaunchKernelGGL(wino_fused8_kernel<false>, grid, dim3(512), WF_LDS, st, a);
     SSDHIP_CHECK_LAUNCH();
     return a.MB;      // rows of the BatchNorm partial table
