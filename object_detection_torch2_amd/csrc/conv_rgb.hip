@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void conv_rgb3x3_kernel(const float4* __restri
 #pragma unroll
     for (int j = 0; j < NT; ++j) { bv[j] = bias ? bias[prow + 32 * j] : 0.f; s1[j] = 0.f; s2[j] = 0.f; }
 
-    for (int64_t tile = wave; tile < tiles; tile += nwaves) {
+    // the A operand of the NEXT tile is requested before the current tile's MFMAs and stores: one tile of latency cover per wave
+    auto fetch = [&](int64_t tile, float4* a) -> unsigned {
         const int64_t p = tile * 32 + prow;               // this lane's pixel (A-operand row)
         const bool pv = p < M;
         const int64_t pc = pv ? p : M - 1;
@@ -45,20 +46,27 @@ __global__ __launch_bounds__(256) void conv_rgb3x3_kernel(const float4* __restri
         const int y = rem / W, xx = rem - y * W;
         // five unconditional loads (addresses clamped into the image) issued back to back, zeroed afterwards where the tap lies
         // outside: loads under `ok ? load : 0` compile to exec-masked load / wait pairs, one memory latency each
-        float4 a[5];
-        bool ok[5];
-#pragma unroll
+        unsigned okmask = 0;                              // applied by the caller when it starts to use the values (not here: the
+#pragma unroll                                            // selects would wait for the loads in front of the current tile's MFMAs)
         for (int q = 0; q < 5; ++q) {
             const int t = 2 * q + half;
             const int r = t / 3, s = t - 3 * r;
             const int yy = y + r - 1, xs = xx + s - 1;
-            ok[q] = pv && t < 9 && (unsigned)yy < (unsigned)H && (unsigned)xs < (unsigned)W;
+            okmask |= (unsigned)(pv && t < 9 && (unsigned)yy < (unsigned)H && (unsigned)xs < (unsigned)W) << q;
             const int yc = min(max(yy, 0), H - 1), xc = min(max(xs, 0), W - 1);
             a[q] = x[((size_t)n * H + yc) * W + xc];
         }
+        return okmask;
+    };
+    float4 a[5], an[5];
+    unsigned mk = 0, mkn = 0;
+    if (wave < tiles) mk = fetch(wave, a);
 #pragma unroll
-        for (int q = 0; q < 5; ++q)
-            if (!ok[q]) a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < 5; ++q)
+        if (!((mk >> q) & 1u)) a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t tile = wave; tile < tiles; tile += nwaves) {
+        const bool more = tile + nwaves < tiles;
+        if (more) mkn = fetch(tile + nwaves, an);
         f32x16 acc[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j)
@@ -85,6 +93,10 @@ __global__ __launch_bounds__(256) void conv_rgb3x3_kernel(const float4* __restri
                     s1[j] += v; s2[j] += v * v;
                 }
             }
+        }
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) a[q] = ((mkn >> q) & 1u) ? an[q] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     if (stats != nullptr) {
