@@ -9,8 +9,10 @@ Replaces the ATen dispatch behind SSD.forward (model/ssd.py:86-106) and the auto
   * the VGG part is frozen (ssd.py:31-32): no graph, no saved activations, no dgrad/wgrad for conv_1_1..conv_5_3
     (SSD.finetune_backbone() un-freezes it: the same backward loop then runs down to conv_1_1, through the max-pools);
   * gradients land in one flat fp32 buffer (views per parameter) so data-parallel all-reduce is a few large RCCL calls;
-  * two HIP streams: the detector heads (forward) and every weight gradient (backward) run on a side stream next to the
-    layer chain -- the small late-stage launches cannot fill 256 CUs one at a time (SSD_SINGLE_STREAM=1 disables it).
+  * three HIP streams: the detector heads (forward) and every weight gradient (backward) run on a side stream next to the
+    layer chain, the frozen backbone on its own stream across steps (SSD_SINGLE_STREAM=1 disables both);
+  * the deep 3x3 layers (conv_3_2 .. conv_6_1, heads on >= 16-px maps) run through Winograd F(4x4,3x3) (csrc/winograd4.hip),
+    conv_1_2 .. conv_3_1 through the one-kernel F(2x2) form (SSD_WINOGRAD=f2: F(2x2) everywhere).
 """
 import contextlib
 import ctypes
@@ -651,7 +653,7 @@ class Engine:
                 elif self._wino4_ok(c, g):
                     rows = self._conv_winograd4(c, cur, cur_xs, z, ws, N, g['hi'], g['wi'], g, ws['partial'] if training else None)
                 elif self._fused_ok(c, g, N):
-                    # conv_1_2 .. conv_3_3 (300x300 .. 75x75 maps): the one-kernel Winograd form (wino_fused.hip); nothing of the
+                    # conv_1_2 .. conv_3_1 (300x300 .. 75x75 maps, K <= 128; conv_3_2 / conv_3_3 too under SSD_WINOGRAD=f2): the one-kernel Winograd form (wino_fused.hip); nothing of the
                     # Winograd domain in HBM.  Measured against the paths below (scripts/wf_bench.py, batch 32): conv_1_2 1.57 vs 1.80 ms,
                     # conv_2_1 0.71 vs 0.86, conv_2_2 1.17 vs 1.6-1.9, conv_3_1 0.71 vs 0.79, conv_3_2/3 1.18 vs 1.23; from the 38x38
                     # maps down the three-pass form wins (its 128x128 GEMM tiles need half the L2 -> LDS bytes per flop)
