@@ -614,7 +614,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         return f;
     };
     const float ysign = hh ? -1.f : 1.f;
-    const unsigned wr_lane = (unsigned)(tile_l * 32 + ((q ^ ((tile_l >> 3) & 1)) * 16) + half * 8);
+    // A-image rows are 32 B (8 k); the two 16-B halves of row r are swapped where ((r >> 2) ^ (r >> 3)) & 1.  Bit 3 keeps the MFMA feed's
+    // ds_read_b64 conflict-free (64 banks: rows r and r + 8 of a 32-lane group meet); bit 2 does the same for these ds_write_b64
+    // (stores bank modulo 32 dwords in groups of 16 lanes = 8 tiles: rows r and r + 4 met 2-way with bit 3 alone -- 2.6e7 conflict cycles per launch)
+    const unsigned wr_lane = (unsigned)(tile_l * 32 + ((q ^ (((tile_l >> 2) ^ (tile_l >> 3)) & 1)) * 16) + half * 8);
     const unsigned x_wr = lds0 + (unsigned)(WF_A_OFF + (hh ? 12 : 0) * WF_PLANE) + wr_lane;
     const unsigned y_wr = lds0 + (unsigned)(WF_A_OFF + (hh ? 8 : 4) * WF_PLANE) + wr_lane;
     auto rows_of = [&](int j) {
@@ -663,7 +666,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // operand fragments: lane (i = lane & 15, kq = lane >> 4) takes the 8 bytes (channels 2 kq, 2 kq + 1) of row i of the wave's 16
     // tile rows / of each of its two groups of 16 channel rows; the 16-B halves of a row are swapped where (row >> 3) & 1
     const int li = lane & 15, kq = lane >> 4;
-    const unsigned f_lo = (unsigned)(li * 32 + ((kq * 8) ^ (((li >> 3) & 1) * 16)));
+    const unsigned f_lo = (unsigned)(li * 32 + ((kq * 8) ^ ((((li >> 2) ^ (li >> 3)) & 1) * 16)));
     const unsigned a_rd = lds0 + (unsigned)(WF_A_OFF + 16 * wm * 32) + f_lo;
     const unsigned b_rd = lds0 + (unsigned)(WF_B_OFF + wn * 1024 + li * 64 + ((kq ^ ((4 - (li >> 2)) & 3)) * 16));
     const int co0 = n0 + 32 * wn + 2 * li;                 // this lane's two output channels: co0 (column group 0), co0 + 1 (group 1)
