@@ -422,7 +422,17 @@ class Engine:
         p.R, p.S, p.stride, p.pad, p.KP, p.mode, p.accumulate = 1, 1, 1, 0, spec.cin, 0, 0
         p.tile = 128128 if cp <= 128 else 128064
         p.rows_per_img, p.w_img_stride = tp, rows * spec.cin
-        self._plane_gemm(p, tp, spec.cin, cp, rows * spec.cin, f'winograd4 gemm {spec.name}', planes=36)
+        if self.prof is None:
+            self._plane_gemm(p, tp, spec.cin, cp, rows * spec.cin, f'winograd4 gemm {spec.name}', planes=36)
+        else:               # roofline leg of bench.py: every launch of the plane GEMM is bracketed, so its average matches rocprofv3's
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._plane_gemm(p, tp, spec.cin, cp, rows * spec.cin, f'winograd4 gemm {spec.name}', planes=36)
+            e1.record()
+            self.prof.append(dict(layer=spec.name + ' (F(4x4) winograd-domain GEMM, head)',
+                                  kernel=('gemm_planes_dma_kernel<128, 128, 0, 8, 0>' if p.tile == 128128 else 'gemm_planes_dma_kernel<128, 64, 0, 4, 0>'),
+                                  direct_flops=2.0 * N * h * w * spec.cin * spec.cout * 9,
+                                  flops=2.0 * 36 * tp * spec.cin * cp, e0=e0, e1=e1))
         _lib.check(L.ssdhip_winograd4_output_head(_lib.ptr(Mo), _lib.ptr(bias), out_ptr, out_batch_stride, N, h, w, spec.cout, cp, tp, st),
                    f'winograd4_output_head {spec.name}')
 
