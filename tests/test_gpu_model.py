@@ -532,3 +532,36 @@ def test_winograd_f2_switch_runs_the_same_network(env, monkeypatch):
             continue
         a, b = g4[k].double().flatten(), g2[k].double().flatten()
         assert torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30) > 0.998, k
+
+
+def test_pool_fusion_is_bit_identical(env, monkeypatch):
+    """conv_1_2 / conv_2_2 store the pooling windows' max and min of z instead of z (ssdhip_wino_fused_conv_pool + ssdhip_bn_relu_select);
+    SSD_NO_POOL_FUSE=1 writes z and runs the pool pass.  relu(bn(.)) is monotonic in z, so both must give the same bits: outputs, loss,
+    every gradient, BatchNorm running statistics -- in train and in eval mode."""
+    O, synth = env['O'], env['synth']
+    ims = torch.from_numpy(synth.images(44, 3)).to(DEV)
+    tg = torch.from_numpy(synth.targets(54, 3, g_max=6)).to(DEV)
+    res = {}
+    for off in ('0', '1'):
+        monkeypatch.setenv('SSD_NO_POOL_FUSE', off)
+        net = make_net(env)
+        # negative and zero BatchNorm scales in front of both fused pools (gamma < 0 selects the window minimum)
+        with torch.no_grad():
+            for name in ('bn_1_2', 'bn_2_2'):
+                g = net.features[name].weight
+                g[::3] = -g[::3]
+                g[1::7] = 0.0
+        df = net.default_bboxes.to(DEV)
+        out = net(ims)
+        assert net._engine()._pool_fuse == (off == '0')
+        loss = net.loss(out, tg, df)
+        loss.backward()
+        net.eval()
+        with torch.no_grad():
+            out_eval = net(ims)
+        res[off] = (out.detach().clone(), loss.item(), [p.grad.detach().clone() for _, p in net.named_train_params()],
+                    net.features['bn_2_2'].running_var.clone(), net.features['bn_3_1'].running_mean.clone(), out_eval.clone())
+    a, b = res['0'], res['1']
+    assert torch.equal(a[0], b[0]) and a[1] == b[1] and torch.equal(a[5], b[5])
+    assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
+    assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
