@@ -426,6 +426,8 @@ def main():
                                                  if args.dtype == 'fp32' else 'see precision'),
                     conv_flop_roofline_frac=round(value / world * (gf_train if args.mode == 'train' else gf_fwd)
                                                   / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
+                    conv_flop_roofline_note=('direct-convolution flops of SURVEY 8(d) per second against the fp32 MFMA peak; it exceeds 1 because the Winograd '
+                                             'layers execute 2.25x (F(2x2)) to 4x (F(4x4)) fewer MFMA flops than that count: `roofline` prices executed flops'),
                     mean_loss=round(final_loss, 4), ranks=(dist.get_world_size() if world > 1 else 1))
         if comm is not None:
             # comm_ms_per_step: the gradient all-reduce of one step by itself (HIP events, max over ranks); the step hides most of
