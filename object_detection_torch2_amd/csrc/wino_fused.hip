@@ -928,6 +928,7 @@ static int wino_fused_launch(const float* x, const float* upk, const float* bias
     const int cus = ssdhip_cu_count();              // one persistent block fills a CU (160 KiB of LDS): never more blocks than CUs
     const int cap = max_blocks > 0 && max_blocks < cus ? (max_blocks < a.NB ? a.NB : max_blocks) : cus;
     int G = items < cap ? (int)items : cap / a.NB * a.NB;
+    if (items >= cap && cap >= 8 * a.NB) G = cap / (8 * a.NB) * (8 * a.NB);      // keep the XCD-band item order (needs G % (8 NB) == 0) for any cap
     dim3 grid((unsigned)G), block(256);
     hipStream_t st = (hipStream_t)stream;
 #ifdef SSDHIP_PROBES
