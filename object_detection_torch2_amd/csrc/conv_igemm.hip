@@ -619,6 +619,7 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
         a.tpb = (int)(tiles / (256 * 6));
         if (a.tpb < 1 || a.tpb == 2) a.tpb = 1;
         if (a.tpb > 8) a.tpb = 8;
+        if (p->Cin >= 256 && a.tpb > 3) a.tpb = 3;      // K >= 256 (conv_3_2 / conv_3_3 F(4x4) planes, 6,552 tiles): 3 tiles 532-537 us, 4 tiles 544-553 (three runs)
         // plain row-major planes: stage with the LDS-DMA engine (gemm_planes.hip) unless tile code 9xxxxxx asks for the
         // register-staged kernel (A/B comparison in scripts/wino_bench.py)
         int probe = 0;
