@@ -122,6 +122,7 @@ class Engine:
         if self._wino_mode not in ('f2', 'f4'):
             raise ValueError(f"SSD_WINOGRAD must be 'f2' or 'f4', got {self._wino_mode!r}")
         self._pool_fuse = os.environ.get('SSD_NO_POOL_FUSE') != '1'      # A/B: conv + 2x2 max-pool without materialising z (conv_1_2, conv_2_2)
+        self._w4_max_map = int(os.environ.get('SSD_W4_MAX_MAP', '160'))     # largest map side on the F(4x4) passes (SSD512: conv_3_2 / conv_3_3 at 128 px)
         self._w4_min_cin = int(os.environ.get('SSD_W4_MIN_CIN', '256'))      # A/B: 128 also routes conv_3_1 (K = 128) to the F(4x4) passes
         self._cus = None       # compute units of the device (first forward): the persistent backbone grids take 7/8 of them beside the tail
         self._wf_blocks_env = os.environ.get('SSD_WF_BLOCKS')
@@ -315,7 +316,7 @@ class Engine:
         return (self._wino_mode == 'f4' and (sizing or not self.bf16) and (c.frozen or first_tail) and not c.is_head
                 and c.k == 3 and c.stride == 1 and c.pad == 1
                 and c.cin >= self._w4_min_cin and c.cin % 32 == 0 and c.cout % 4 == 0 and 256 % (c.cout // 4) == 0
-                and 8 <= min(g['hi'], g['wi']) and max(g['hi'], g['wi']) <= 80)
+                and 8 <= min(g['hi'], g['wi']) and max(g['hi'], g['wi']) <= self._w4_max_map)
 
     def _wino4_plan(self, c, g, N):
         """(tiles, padded tiles per plane, GEMM tile code) of an F(4x4) layer: 128x128 GEMM tiles once the grid has > 2000 of them, else
