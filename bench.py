@@ -26,15 +26,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 
 
 def host_cores():
-    """CPU cores this process may actually use: cgroup quota if set (the GPU box gives one GPU's share), else affinity."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    try:
-        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
-        if quota != 'max':
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        pass
-    return min(n, 16) if n > 64 else n      # unrestricted many-core host: use the documented 16-core share of one GPU
+    from object_detection_torch2_amd.parallel import host_cores as hc
+    return hc()
 
 
 def cpu_model():
@@ -111,45 +104,11 @@ def step_gflop(eng, imsize):
     return fwd / 1e9, (fwd + wgrad + dgrad) / 1e9
 
 
-def free_port():
-    import socket
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        return s.getsockname()[1]
-
-
 def launch_ranks(n):
-    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
-    MASTER_* in their environment) from this process, which has not touched the GPU and never does; relay rank 0's stdout (the
-    one JSON line), send the other ranks' stdout to stderr; the first failing rank ends the job with its exit code."""
-    import subprocess
-    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()))
-    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL peer mappings fail without it on this driver
-    env.setdefault('OMP_NUM_THREADS', str(max(1, host_cores() // n)))
-    procs = []
-    for r in range(n):
-        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
-                                      stdout=None if r == 0 else sys.stderr))
-    rc = 0
-    live = list(procs)
-    while live and rc == 0:
-        time.sleep(0.2)
-        for p in list(live):
-            code = p.poll()
-            if code is not None:
-                live.remove(p)
-                if code != 0:
-                    rc = code if code > 0 else 128 - code
-                    print(f'bench.py: rank {procs.index(p)} exited with code {code}; stopping the other ranks', file=sys.stderr)
-    for p in live:                       # a rank failed: its peers would wait in a collective forever
-        p.terminate()
-    for p in live:
-        try:
-            p.wait(timeout=20)
-        except subprocess.TimeoutExpired:
-            p.kill()
-    return rc
+    """`python bench.py --gpus N` without a launcher: N fresh rank processes started from this process, which has not touched the
+    GPU and never does (parallel.launch_local_ranks)."""
+    from object_detection_torch2_amd.parallel import launch_local_ranks
+    return launch_local_ranks(n, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
 
 
 def dry_run(args):
@@ -207,6 +166,12 @@ def main():
                     help='extension (SURVEY 8(f)-4): un-freeze VGG16-bn (187.9 GFLOP/img instead of 72.2); never the headline')
     ap.add_argument('--mode', choices=['train', 'infer'], default='train',
                     help='train (headline, BASELINE configs[2]) or infer (configs[1]: forward + decode + score + NMS)')
+    ap.add_argument('--no-graph', action='store_true',
+                    help='enqueue every step from Python (the eager engine) instead of replaying the captured step (graph_step.py)')
+    ap.add_argument('--allreduce', choices=['allreduce', 'rs_ag'], default=os.environ.get('SSD_ALLREDUCE', 'allreduce'),
+                    help='N > 1: gradient exchange as all-reduce buckets or as reduce-scatter + all-gather (SURVEY 8(e))')
+    ap.add_argument('--grad-dtype', choices=['fp32', 'bf16'], default=os.environ.get('SSD_GRAD_DTYPE', 'fp32'),
+                    help='N > 1: payload of the gradient exchange (bf16 halves the bytes; the sum is taken in bf16)')
     ap.add_argument('--dry-run', action='store_true', help='no GPU: rehearse the launcher, rendezvous and all-reduce over gloo (CPU tests)')
     args = ap.parse_args()
 
@@ -236,7 +201,7 @@ def main():
     if world > 1:
         parallel.broadcast_module(net)      # replicas start from rank 0's weights whatever each process's RNG state was
     df = net.default_bboxes.to(dev)
-    world_n = parallel.attach(net) if world > 1 else 1
+    world_n = parallel.attach(net, mode=args.allreduce, payload=args.grad_dtype) if world > 1 else 1
     opt = FusedAdam(net.train_params(), lr=1e-3, weight_decay=5e-4, grad_scale=1.0 / world_n, on_step=net.hip_weights_changed)
     B = args.batch
     ims = torch.from_numpy(synth.images(100 + rank, B, args.imsize)).to(dev)       # this rank's shard of the global batch
@@ -258,7 +223,7 @@ def main():
             hip_utils.non_maximum_suppression(out)
         running.add_(out[0, 0, 0])
 
-    def step():
+    def eager_step():
         if args.mode == 'infer':
             return infer_step()
         opt.zero_grad()
@@ -268,19 +233,47 @@ def main():
         opt.step()
         running.add_(loss.detach())
 
+    runner, step_mode = None, 'eager: every launch enqueued from Python'
+    use_graph = (args.mode == 'train' and not args.no_graph and not args.finetune_backbone and os.environ.get('SSD_NO_GRAPH') != '1'
+                 and os.environ.get('SSD_SINGLE_STREAM') != '1')
+
+    def step():
+        if runner is None:
+            return eager_step()
+        runner.feed(ims, resident)             # frozen backbone of the NEXT step on its own stream ...
+        running.add_(runner.step(tgs))         # ... beside this step's tail forward + loss + backward + Adam
+
     # the caller's stream carries the tail (small dependent launches); run it above the backbone stream's priority
     main_stream = torch.cuda.Stream(device=dev, priority=-1) if os.environ.get('SSD_STREAM_PRIO', '1') == '1' else torch.cuda.current_stream()
     main_stream.wait_stream(torch.cuda.current_stream())
     torch.cuda.set_stream(main_stream)
-    for _ in range(args.warmup):
-        step()
     eng = net._engine()
+    if use_graph:
+        # a few eager steps first (Adam moments exist, allocator warm), then the captured step; a capture that fails for any reason
+        # leaves the eager path (and says so in the line)
+        for _ in range(min(2, args.warmup)):
+            eager_step()
+        try:
+            from object_detection_torch2_amd.graph_step import GraphedTrainStep
+            runner = GraphedTrainStep(net, opt, df, ims.shape, tgs.shape)
+            runner.feed(ims, resident)         # prime the pipeline: from here on every step() pairs one backbone pass with one tail
+            step_mode = ('HIP graphs: backbone(i+1) [1 graph, own stream] beside tail(i) = heads + trainable layers + loss + backward + Adam '
+                         f'[{sum(1 for it in runner._tail_items[0] if not isinstance(it, tuple))} graph segment(s)'
+                         + (', RCCL collectives eager between them]' if world > 1 else ']'))
+        except Exception as e:   # noqa: BLE001
+            runner = None
+            step_mode = f'eager (graph capture failed: {type(e).__name__}: {e})'
+            print(f'bench.py: {step_mode}', file=sys.stderr)
+    pre = min(2, args.warmup) if use_graph else 0      # the eager steps in front of the capture count as warm-up steps
+    for _ in range(args.warmup - pre):
+        step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    host_enqueue_ms = (time.perf_counter() - t0) / max(1, args.steps) * 1e3      # host time to enqueue a step (no device wait inside the loop)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -290,6 +283,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     final_loss = running.item() / max(1, args.steps + args.warmup)
+    if runner is not None:
+        running.add_(runner.step(tgs))     # the batch fed ahead of the last timed step
+        runner.drain()
+        graph_runner, runner = runner, None    # the roofline and communication legs below bracket single launches: eager steps
     if not args.no_roofline:
         # The roofline leg runs on EXTRA steps right behind the timed region, never inside it: creating and recording an event pair
         # per large launch costs the host ~1 ms per step, which the bf16 step (4.8 ms of device time for 3.5 ms of enqueueing)
@@ -303,8 +300,11 @@ def main():
     def aggregate(records):
         agg = {}
         for r in records:
-            a = agg.setdefault(r['kernel'], dict(ms=0.0, flops=0.0, n=0, layers=set(), direct=0.0, peak=r.get('peak_tflops', FP32_MFMA_PEAK_TFLOPS)))
-            a['ms'] += r['e0'].elapsed_time(r['e1']); a['flops'] += r['flops']; a['n'] += 1; a['layers'].add(r['layer'])
+            a = agg.setdefault(r['kernel'], dict(ms=0.0, flops=0.0, n=0, layers=set(), direct=0.0, padded=0.0, peak=r.get('peak_tflops', FP32_MFMA_PEAK_TFLOPS)))
+            # `flops` = the ALGORITHMIC flops of the launch (for a Winograd-domain GEMM: 2 * planes * tiles * Cin * Cout with the real tile and
+            # channel counts); `padded` = what the launch executes including tile / channel padding (det_4_3: 100 -> 128 channels)
+            a['ms'] += r['e0'].elapsed_time(r['e1']); a['flops'] += r.get('flops_unpadded', r['flops']); a['padded'] += r['flops']
+            a['n'] += 1; a['layers'].add(r['layer'])
             a['direct'] += r.get('direct_flops', r['flops'])
         return agg
 
@@ -313,20 +313,24 @@ def main():
         agg = aggregate(eng.prof)
         name, a = max(agg.items(), key=lambda kv: kv[1]['ms'])
         ach = a['flops'] / (a['ms'] * 1e-3) / 1e12
-        traffic = None       # HBM-side bytes per launch from the committed PMC passes (scripts/collect_pmc.sh + pmc_summary.py)
-        try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r03_pmc_summary.json')))
-            traffic = round(pmc[name]['hbm_bytes_per_launch'])
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic, traffic_source = None, None   # HBM-side bytes per launch: NOT measured in this run (PMC passes need rocprofv3 around the
+        for pmc_file in ('r04_pmc_summary.json', 'r03_pmc_summary.json'):     # process): read from the committed summary of scripts/collect_pmc.sh
+            try:
+                pmc = json.load(open(os.path.join(ROOT, 'profiles', pmc_file)))
+                traffic = round(pmc[name]['hbm_bytes_per_launch'])
+                traffic_source = (f'profiles/{pmc_file} (separate rocprofv3 --pmc passes of this workload: FETCH_SIZE x2 per the gfx950 '
+                                  'correction + WRITE_SIZE; committed file, not collected by this run)')
+                break
+            except (OSError, KeyError, ValueError):
+                pass
         notes = []
         if a['direct'] > a['flops'] * 1.01:
             notes.append('achieved/frac count the MFMA flops this kernel executes; the Winograd-domain GEMMs stand for '
                          f"{a['direct'] / a['flops']:.2f}x as many direct-convolution flops")
         peak = a['peak']          # fp32 MFMA peak, or the dense bf16 MFMA peak for the bf16 patch convolution (MI355X_MICROARCH.md)
         roof = dict(bound='mfma', kernel=name, achieved=round(ach, 2), peak=peak, unit='TFLOP/s',
-                    frac=round(ach / peak, 4), traffic=traffic, launches=a['n'],
-                    algorithmic_flop_per_launch=round(a['flops'] / a['n']),
+                    frac=round(ach / peak, 4), traffic=traffic, traffic_source=traffic_source, launches=a['n'],
+                    algorithmic_flop_per_launch=round(a['flops'] / a['n']), executed_flop_per_launch_incl_padding=round(a['padded'] / a['n']),
                     avg_launch_ms=round(a['ms'] / a['n'], 4), layers=sorted(a['layers']),
                     conv_fwd_tflops_launches_over_10_gflop=round(sum(v['flops'] for v in agg.values()) / (sum(v['ms'] for v in agg.values()) * 1e-3) / 1e12, 2))
         if not eng.single_stream:
@@ -388,6 +392,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         alone_ms = e0.elapsed_time(e1) / reps
+        hook_desc = hook.describe()
         eng.dist_hook = None
         k = max(1, min(args.steps, 10))
         step()
@@ -401,7 +406,7 @@ def main():
         t = torch.tensor([(time.perf_counter() - t1) / k * 1e3, alone_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         eng.dist_hook = hook
-        comm = dict(alone_ms=round(t[1].item(), 3), step_ms_without=round(t[0].item(), 3), bytes=flat.numel() * 4)
+        comm = dict(alone_ms=round(t[1].item(), 3), step_ms_without=round(t[0].item(), 3), bytes=flat.numel() * 4, describe=hook_desc)
 
     gf_train, gf_fwd = GFLOP_PER_IMAGE_TRAIN, 62.747
     if args.imsize != 300 or args.finetune_backbone:
@@ -424,18 +429,24 @@ def main():
                                                  if eng._wino_mode == 'f4' else
                                                  'fp32 MFMA throughout; 3x3/s1/p1 layers: Winograd F(2x2,3x3) everywhere (SSD_WINOGRAD=f2)')
                                                  if args.dtype == 'fp32' else 'see precision'),
-                    conv_flop_roofline_frac=round(value / world * (gf_train if args.mode == 'train' else gf_fwd)
-                                                  / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
-                    conv_flop_roofline_note=('direct-convolution flops of SURVEY 8(d) per second against the fp32 MFMA peak; it exceeds 1 because the Winograd '
-                                             'layers execute 2.25x (F(2x2)) to 4x (F(4x4)) fewer MFMA flops than that count: `roofline` prices executed flops'),
+                    direct_equiv_vs_fp32_peak=round(value / world * (gf_train if args.mode == 'train' else gf_fwd)
+                                                    / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
+                    direct_equiv_note=('NOT a roofline fraction: direct-convolution flops of SURVEY 8(d) per second over the fp32 MFMA peak; it exceeds 1 because the '
+                                       'Winograd layers execute 2.25x (F(2x2)) to 4x (F(4x4)) fewer MFMA flops than that count; `roofline` prices the flops a kernel executes'),
+                    step_mode=step_mode, host_enqueue_ms_per_step=round(host_enqueue_ms, 3),
                     mean_loss=round(final_loss, 4), ranks=(dist.get_world_size() if world > 1 else 1))
         if comm is not None:
             # comm_ms_per_step: the gradient all-reduce of one step by itself (HIP events, max over ranks); the step hides most of
             # it behind the last weight gradients and the next step's backbone -- comm_exposed_ms_per_step is what is left
             line['comm_ms_per_step'] = comm['alone_ms']
             line['comm_exposed_ms_per_step'] = round(dt / args.steps * 1e3 - comm['step_ms_without'], 3)
-            line['comm'] = dict(collective='all-reduce(sum) of the flat fp32 gradient buffer, 2 + 1 buckets', bytes=comm['bytes'],
-                                backend=dist.get_backend(), ms_per_step_without_allreduce=comm['step_ms_without'])
+            d = comm['describe']
+            line['rccl_ranks_seen'] = d['ranks_seen']           # from the communicator, not from the command line
+            line['comm'] = dict(collective=('all-reduce(sum)' if d['mode'] == 'allreduce' else 'reduce-scatter + all-gather (in place)')
+                                + f" of the flat gradient buffer, {d['payload']} payload, {d['buckets_early']} early bucket(s) + 1 late",
+                                bytes=comm['bytes'], backend=d['backend'], mode=d['mode'], payload=d['payload'],
+                                per_collective=[dict(kind=k, elements=n, wire_bytes_per_rank=b) for k, n, b in d['collectives_last_step']],
+                                ms_per_step_without_allreduce=comm['step_ms_without'])
         else:
             line['comm_ms_per_step'] = 0.0
         if roof is not None:

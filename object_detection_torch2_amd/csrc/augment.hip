@@ -149,7 +149,7 @@ int64_t ssdhip_augment_ws_bytes(int N) { return (int64_t)N * MEAN_BLOCKS * sizeo
 
 int ssdhip_augment_batch(const uint8_t* src_nhwc_u8, const float* params, int N, int H, int W, float* out_nchw, void* ws, void* stream) {
     SSDHIP_REQUIRE(src_nhwc_u8 && params && out_nchw && ws, "augment: null pointer");
-    SSDHIP_REQUIRE(N > 0 && H > 0 && W > 0 && (int64_t)H * W < (1 << 30), "augment: bad shape");
+    SSDHIP_REQUIRE(N > 0 && H > 0 && W > 0 && elems_below(1ll << 30, H, W), "augment: bad shape");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(augment_mean_kernel, dim3(MEAN_BLOCKS, N), dim3(256), 0, st, src_nhwc_u8, params, H * W, (double*)ws);
     hipLaunchKernelGGL(augment_apply_kernel, dim3(cdiv((int64_t)H * W, 256), N), dim3(256), 0, st, src_nhwc_u8, params, (const double*)ws, H, W,

@@ -46,6 +46,20 @@ extern "C" int ssdhip_cu_count(void);
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// a * b * c * d * e < limit for non-negative factors, evaluated without overflowing int64 (the size checks of the launchers take extents
+// straight from the caller: four 31-bit extents multiply to 2^124).  A negative factor fails the check.  Found by `make asan` (UBSan).
+static inline bool elems_below(int64_t limit, int64_t a, int64_t b = 1, int64_t c = 1, int64_t d = 1, int64_t e = 1) {
+    const int64_t f[5] = {a, b, c, d, e};
+    int64_t v = 1;
+    for (int i = 0; i < 5; ++i) {
+        if (f[i] < 0) return false;
+        if (f[i] == 0) return limit > 0;
+        if (v > (limit - 1) / f[i]) return false;
+        v *= f[i];
+    }
+    return v < limit;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);

@@ -409,7 +409,7 @@ int ssdhip_conv_bf16(const void* a, const void* wpk, const float* bias, void* z,
     SSDHIP_REQUIRE(a && wpk && z && N > 0 && H > 0 && W > 0 && max_blocks >= 0, "conv_bf16: bad arguments");
     SSDHIP_REQUIRE(Cin >= 32 && Cin % 32 == 0 && Cout > 0 && Cout % 64 == 0, "conv_bf16: Cin must be a multiple of 32 and Cout of 64");
     const int64_t abytes = ssdhip_conv_bf16_act_bytes(N, H, W, Cin);
-    SSDHIP_REQUIRE(abytes > 0 && abytes < (1ll << 32) && (int64_t)N * H * W * Cout < (1ll << 31), "conv_bf16: the haloed input must stay below 4 GiB (32-bit byte offsets) and the output below 2^31 elements");
+    SSDHIP_REQUIRE(abytes > 0 && abytes < (1ll << 32) && elems_below(1ll << 31, N, H, W, Cout), "conv_bf16: the haloed input must stay below 4 GiB (32-bit byte offsets) and the output below 2^31 elements");
     SSDHIP_REQUIRE(W >= 14, "conv_bf16: map too narrow (W >= 14)");
     static DeviceOnce attr;
     if (const int dev = attr.pending(); dev != DeviceOnce::kDone) {

@@ -182,7 +182,7 @@ int ssdhip_conv_c64(const float* x, const float* wimg, const float* bias, const 
     SSDHIP_REQUIRE(x && wimg && z && N > 0 && H > 0 && W > 0, "conv_c64: bad arguments");
     SSDHIP_REQUIRE(Cout == 64 || Cout == 128 || Cout == 256, "conv_c64: Cout must be 64, 128 or 256");
     SSDHIP_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv_c64: in_scale and in_shift go together");
-    SSDHIP_REQUIRE((int64_t)N * H * W * 64 < (1ll << 31), "conv_c64: tensor too large");
+    SSDHIP_REQUIRE(elems_below(1ll << 31, N, H, W, 64), "conv_c64: tensor too large");
     static DeviceOnce attr;
     const size_t lds = (size_t)(W_IMAGE + 128) * sizeof(float);
     if (const int dev = attr.pending(); dev != DeviceOnce::kDone) {

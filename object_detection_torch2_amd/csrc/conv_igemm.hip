@@ -581,7 +581,7 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
     SSDHIP_REQUIRE(p->mode == 0 || p->mode == 1, "conv2d: mode 0 (fwd) or 1 (dgrad)");
     SSDHIP_REQUIRE(!(p->mode == 1 && p->in_scale), "conv2d: no input transform in dgrad mode");
     SSDHIP_REQUIRE((p->in_scale == nullptr) == (p->in_shift == nullptr), "conv2d: in_scale and in_shift go together");
-    SSDHIP_REQUIRE((int64_t)p->N * p->Hi * p->Wi * p->Cin < (1ll << 30) && (int64_t)p->N * p->Ho * p->Wo < (1ll << 31),
+    SSDHIP_REQUIRE(elems_below(1ll << 30, p->N, p->Hi, p->Wi, p->Cin) && elems_below(1ll << 31, p->N, p->Ho, p->Wo),
                    "conv2d: input tensor must stay below 4 GiB (32-bit byte offsets)");
     if (p->mode == 0) {
         SSDHIP_REQUIRE(p->Ho == (p->Hi + 2 * p->pad - p->R) / p->stride + 1 && p->Wo == (p->Wi + 2 * p->pad - p->S) / p->stride + 1,
@@ -615,8 +615,10 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
         // short-K plane GEMMs: amortise pipeline fill/drain over several m-tiles, but keep >= ~6 blocks per CU.  Two tiles per block
         // measured worse than one AND than three on every shape (3,600-tile GEMMs of the 36-plane F(4x4) layers: 537 vs 505 / 507 us on
         // conv_4_2, 287 vs 277 / 276 on conv_4_1; scripts/w4_bench.py with tile codes 40..49 of the probe build), so 2 becomes 1
+        // (measured on conv_4_1 / conv_4_2 (K = 256 / 512, 3,600 tiles) and conv_3_2 (K = 256, 6,552 tiles) of SSD300 at batch 32 only;
+        // other shapes inherit the rule unmeasured)
         const int64_t tiles = (int64_t)a.MB * a.NB;
-        a.tpb = (int)(tiles / (256 * 6));
+        a.tpb = (int)(tiles / ((int64_t)ssdhip_cu_count() * 6));
         if (a.tpb < 1 || a.tpb == 2) a.tpb = 1;
         if (a.tpb > 8) a.tpb = 8;
         if (p->Cin >= 256 && a.tpb > 3) a.tpb = 3;      // K >= 256 (conv_3_2 / conv_3_3 F(4x4) planes, 6,552 tiles): 3 tiles 532-537 us, 4 tiles 544-553 (three runs)

@@ -128,7 +128,7 @@ int ssdhip_conv_rgb3x3(const float* x_nhwc4, const float* w_oihw, const float* b
                        void* stream) {
     SSDHIP_REQUIRE(x_nhwc4 && w_oihw && z && N > 0 && H > 0 && W > 0, "conv_rgb3x3: bad arguments");
     SSDHIP_REQUIRE(Cout == 64, "conv_rgb3x3: built for Cout = 64 (VGG16 conv_1_1)");
-    SSDHIP_REQUIRE((int64_t)N * H * W < (1ll << 31), "conv_rgb3x3: tensor too large");
+    SSDHIP_REQUIRE(elems_below(1ll << 31, N, H, W), "conv_rgb3x3: tensor too large");
     hipLaunchKernelGGL(conv_rgb3x3_kernel<2>, dim3(rgb_grid((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const float4*>(x_nhwc4), w_oihw, bias, z, stats, N, H, W);
     SSDHIP_CHECK_LAUNCH();

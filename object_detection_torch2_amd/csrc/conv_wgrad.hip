@@ -639,7 +639,7 @@ int ssdhip_conv2d_wgrad(const ssdhip_wgrad_params* p, void* stream) {
     SSDHIP_REQUIRE(p->R == p->S && (p->R == 1 || p->R == 3), "wgrad: 1x1 or 3x3 kernels");
     SSDHIP_REQUIRE(p->compute == 0 || p->compute == 1, "wgrad: compute must be 0 (fp32) or 1 (bf16 operands)");
     SSDHIP_REQUIRE((p->in_scale == nullptr) == (p->in_shift == nullptr), "wgrad: in_scale and in_shift go together");
-    SSDHIP_REQUIRE((int64_t)p->N * p->Hi * p->Wi < (1ll << 31), "wgrad: tensor too large");
+    SSDHIP_REQUIRE(elems_below(1ll << 31, p->N, p->Hi, p->Wi), "wgrad: tensor too large");
     WgradArgs a;
     plan(p, a);
     hipStream_t st = (hipStream_t)stream;

@@ -867,7 +867,7 @@ int64_t ssdhip_wino_fused_geo_bytes(int N, int H, int W) {
 int ssdhip_wino_fused_geo(int N, int H, int W, void* geo, void* stream) {
     SSDHIP_REQUIRE(geo && N > 0 && H > 0 && W > 0, "wino_fused_geo: bad arguments");
     const int TH = (H + 1) / 2, TW = (W + 1) / 2;
-    SSDHIP_REQUIRE(TW >= 5 && (int64_t)N * H * W < (1ll << 31), "wino_fused_geo: map too narrow (W >= 9) or too large");
+    SSDHIP_REQUIRE(TW >= 5 && elems_below(1ll << 31, N, H, W), "wino_fused_geo: map too narrow (W >= 9) or too large");
     const int MB = ssdhip_wino_fused_stat_rows(N, H, W);
     SSDHIP_REQUIRE(MB > 0, "wino_fused_geo: bad shape");
     hipLaunchKernelGGL(wino_fused_geo_kernel, dim3(MB), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<int*>(geo), H, W, TH, TW,
@@ -883,7 +883,7 @@ static int wino_fused_launch(const float* x, const float* upk, const float* bias
     SSDHIP_REQUIRE(Cin >= 32 && Cin % 16 == 0 && Cin <= WF_MAXC && Cout > 0 && Cout % WF_COUT == 0,
                    "wino_fused_conv: Cin must be a multiple of 16 in 32..512 and Cout a multiple of 64");
     SSDHIP_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "wino_fused_conv: in_scale and in_shift go together");
-    SSDHIP_REQUIRE((int64_t)N * H * W * Cin * 4 < (1ll << 31) && (int64_t)N * H * W * Cout < (1ll << 31),
+    SSDHIP_REQUIRE(elems_below(1ll << 31, N, H, W, Cin, 4) && elems_below(1ll << 31, N, H, W, Cout),
                    "wino_fused_conv: tensors must stay below 2 GiB (32-bit offsets)");
     SSDHIP_REQUIRE((W + 1) / 2 >= 5, "wino_fused_conv: map too narrow (W >= 9)");
     int abl = 0;

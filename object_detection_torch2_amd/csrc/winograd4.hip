@@ -364,7 +364,7 @@ int ssdhip_winograd4_input(const float* x, const float* in_scale, const float* i
     SSDHIP_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "winograd4_input: in_scale and in_shift go together");
     int T, Tp128;
     SSDHIP_REQUIRE(ssdhip_winograd4_tiles(N, H, W, 128, &T, &Tp128) == SSDHIP_OK && Tp >= T, "winograd4_input: bad shape");
-    SSDHIP_REQUIRE((int64_t)N * H * W * C < (1ll << 31) && (int64_t)36 * Tp * C < (1ll << 33), "winograd4_input: tensor too large");
+    SSDHIP_REQUIRE(elems_below(1ll << 31, N, H, W, C) && elems_below(1ll << 33, 36, Tp, C), "winograd4_input: tensor too large");
     const int TH = (H + 3) / 4, TW = (W + 3) / 4;
     hipStream_t st = (hipStream_t)stream;
     int vec = 2;
@@ -407,7 +407,7 @@ int ssdhip_winograd4_output(const float* Mo, const float* bias, float* y, float*
     SSDHIP_REQUIRE(Cout % 4 == 0 && 256 % (Cout / 4) == 0, "winograd4_output: Cout must be 4 * a divisor of 256 (<= 1024)");
     int T, Tp128;
     SSDHIP_REQUIRE(ssdhip_winograd4_tiles(N, H, W, 128, &T, &Tp128) == SSDHIP_OK && Tp >= T, "winograd4_output: bad shape");
-    SSDHIP_REQUIRE((int64_t)N * H * W * Cout < (1ll << 31), "winograd4_output: tensor too large");
+    SSDHIP_REQUIRE(elems_below(1ll << 31, N, H, W, Cout), "winograd4_output: tensor too large");
     const int TH = (H + 3) / 4, TW = (W + 3) / 4, tb = output_tb(T, Cout / 4);
     hipLaunchKernelGGL(winograd4_output_kernel, dim3(cdiv(T, tb)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const float4*>(Mo), reinterpret_cast<const float4*>(bias), reinterpret_cast<float4*>(y), stats,

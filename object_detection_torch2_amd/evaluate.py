@@ -97,23 +97,25 @@ def evaluate_batches(net, defaults, batches, num_classes=20):
     return result_correct, {c: int(counts[c]) if c < len(counts) else 0 for c in range(num_classes)}
 
 
-def main():
+def main(argv=None):
     parser = argparse.ArgumentParser()
     parser.add_argument('--imsize', type=int, default=300)
     parser.add_argument('--batch_size', type=int, default=2)
     parser.add_argument('--num_workers', type=int, default=8)
     parser.add_argument('--result_dir', type=str, default='./result')
     parser.add_argument('--weights', type=str, default='weights.pth')
+    parser.add_argument('--dtype', type=str, default='fp32', choices=('fp32', 'bf16'), help='arithmetic of the convolutions')
     parser.add_argument('--batches', type=int, default=2, help='synthetic source only')
     parser.add_argument('--data_dirs', type=str, nargs='*', default=None, help='VOC roots (evaluate.py:96: VOC2007 test)')
     parser.add_argument('--data_list', type=str, default='test.txt')
-    args = parser.parse_args()
+    args = parser.parse_args(argv)
 
     out_dir = Path(args.result_dir) / 'detection'
     out_dir.mkdir(parents=True, exist_ok=True)
     device = torch.device('cuda:0')
     net = SSD(num_classes=20 + 1, weights_path=out_dir / args.weights,
-              weights_path_vgg16=Path(args.result_dir) / 'classification' / args.weights)
+              weights_path_vgg16=Path(args.result_dir) / 'classification' / args.weights, imsize=args.imsize)
+    net.set_compute_dtype(args.dtype)
     net.to(device)
     defaults = net.default_bboxes.to(device)
     labelmap = LabelMap('PascalVOC')

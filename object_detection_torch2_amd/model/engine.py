@@ -116,7 +116,7 @@ class Engine:
         self._no_fused = os.environ.get('SSD_NO_FUSED_WINOGRAD') == '1'
         self._no_patch = os.environ.get('SSD_NO_BF16_PATCH') == '1'
         self._z_bf16 = os.environ.get('SSD_BF16_Z', 'bf16') == 'bf16'
-        # frozen 3x3 backbone layers on <= 80-px maps (conv_3_2 .. conv_5_3): Winograd F(4x4,3x3) (csrc/winograd4.hip: 1.78x fewer MFMA flops
+        # frozen 3x3 backbone layers on maps up to SSD_W4_MAX_MAP = 160 px (SSD300: conv_3_2 .. conv_5_3 at 75 .. 19 px; SSD512: from conv_3_2 at 128 px): Winograd F(4x4,3x3) (csrc/winograd4.hip: 1.78x fewer MFMA flops
         # than F(2x2), 2.7x its rounding error, still 8x inside the per-layer bound of the tests); SSD_WINOGRAD=f2 keeps F(2x2) everywhere
         self._wino_mode = os.environ.get('SSD_WINOGRAD', 'f4')
         if self._wino_mode not in ('f2', 'f4'):
@@ -128,6 +128,11 @@ class Engine:
         self._wf_blocks_env = os.environ.get('SSD_WF_BLOCKS')
         self._wf_blocks = int(self._wf_blocks_env) if self._wf_blocks_env is not None else 0
         self._fused_min = int(os.environ.get('SSD_FUSED_MIN', '70'))      # smallest map side that runs on the fused Winograd kernel
+        # phased execution (graph_step.py): the frozen backbone and the trainable tail as two separately enqueued (captured) pieces.
+        # What the tail reads of the backbone -- z and BN state of the stages with a detector head and of the last frozen stage --
+        # exists twice (`parity`), so backbone(i+1) never overwrites what tail(i) still reads and no event crosses between the pieces.
+        self._bb_ctx = {}      # parity -> what forward(phase='backbone') left for forward(phase='tail')
+        self._phased = False   # True while a phased step runs: no cross-step reader events (the double buffers replace them)
 
     # ------------------------------------------------------------------------------------------------ helpers
     def _weight(self, spec):
@@ -156,12 +161,30 @@ class Engine:
             spec.packed_d_key = key
         return spec.packed_d
 
-    def _bn_state(self, name, c, dev):
-        st = self._bn.get(name)
+    def _bn_state(self, name, c, dev, slot=0):
+        key = name if slot == 0 else (name, slot)
+        st = self._bn.get(key)
         if st is None or st['scale'].device != dev:
             st = {k: torch.empty(c, device=dev, dtype=torch.float32) for k in ('scale', 'shift', 'mean', 'invstd')}
-            self._bn[name] = st
+            self._bn[key] = st
         return st
+
+    def shared_stages(self):
+        """Backbone stages whose output the trainable tail reads: those with a detector head (det_4_3 on conv_4_3) and the last frozen
+        stage (input of conv_6_1)."""
+        sh = {i for i in range(self.tail_start) if self.stages[i].head is not None}
+        if 0 < self.tail_start:
+            sh.add(self.tail_start - 1)
+        return sh
+
+    def _alt(self, b, kind, i, like):
+        """Second copy (parity 1) of a hand-over buffer of stage i, allocated on first use."""
+        tab = b.setdefault('alt', {})
+        t = tab.get((kind, i))
+        if t is None:
+            t = torch.zeros_like(like) if kind == 'abf' else torch.empty_like(like)
+            tab[(kind, i)] = t
+        return t
 
     def _geometry(self, H, W):
         """Per-stage spatial sizes for an HxW input."""
@@ -311,7 +334,7 @@ class Engine:
         """Layers on the Winograd F(4x4,3x3) passes: forward of the frozen backbone's 3x3/s1/p1 layers and of the first trainable layer
         on top of it (conv_6_1: its weight gradient reads the backbone's activation and dz, not the forward's products; no data gradient
         is taken through it), K = Cin >= 256 (the transforms move 2.25x the activation bytes each way: they pay for themselves from
-        K = 256 on), maps of 8 .. 80 px (conv_3_2 .. conv_6_1 of SSD300: 75, 38, 19 px; 64 and 32 px of SSD512); fp32 mode only."""
+        K = 256 on), maps of 8 .. SSD_W4_MAX_MAP (160) px (conv_3_2 .. conv_6_1 of SSD300: 75, 38, 19 px; 128, 64 and 32 px of SSD512); fp32 mode only."""
         first_tail = 0 < self.tail_start < len(self.stages) and c is self.stages[self.tail_start].conv
         return (self._wino_mode == 'f4' and (sizing or not self.bf16) and (c.frozen or first_tail) and not c.is_head
                 and c.k == 3 and c.stride == 1 and c.pad == 1
@@ -366,7 +389,7 @@ class Engine:
             self.prof.append(dict(layer=spec.name + ' (F(4x4) winograd-domain GEMM)',
                                   kernel='gemm_planes_dma_kernel<%d, 128, 0, 8, 0>' % (tile // 1000),
                                   direct_flops=2.0 * N * h * w * spec.cin * spec.cout * 9,
-                                  flops=2.0 * 36 * tp * spec.cin * spec.cout, e0=e0, e1=e1))
+                                  flops=2.0 * 36 * tp * spec.cin * spec.cout, flops_unpadded=2.0 * 36 * T * spec.cin * spec.cout, e0=e0, e1=e1))
         return _lib.check(L.ssdhip_winograd4_output(_lib.ptr(Mo), _lib.ptr(bias), _lib.ptr(z), _lib.ptr(stats), 0, N, h, w, spec.cout, tp, st),
                           f'winograd4_output {spec.name}')
 
@@ -402,7 +425,8 @@ class Engine:
                                           'gemm_planes_dma_kernel<%d, 128, 0, 8, 0>' % (p.tile // 1000) if spec.cin >= 256 else
                                           'conv_igemm_kernel<%d, 128, 1, 0, false, false, 0, false>' % (p.tile // 1000)),
                                   direct_flops=2.0 * N * h * w * spec.cin * spec.cout * 9,
-                                  flops=2.0 * 16 * tp * spec.cin * spec.cout, e0=e0, e1=e1))
+                                  flops=2.0 * 16 * tp * spec.cin * spec.cout,
+                                  flops_unpadded=2.0 * 16 * N * ((h + 1) // 2) * ((w + 1) // 2) * spec.cin * spec.cout, e0=e0, e1=e1))
         return _lib.check(L.ssdhip_winograd_output(_lib.ptr(Mo), _lib.ptr(bias), _lib.ptr(z), _lib.ptr(stats), N, h, w, spec.cout, st),
                           f'winograd_output {spec.name}')
 
@@ -433,7 +457,8 @@ class Engine:
             self.prof.append(dict(layer=spec.name + ' (F(4x4) winograd-domain GEMM, head)',
                                   kernel=('gemm_planes_dma_kernel<128, 128, 0, 8, 0>' if p.tile == 128128 else 'gemm_planes_dma_kernel<128, 64, 0, 4, 0>'),
                                   direct_flops=2.0 * N * h * w * spec.cin * spec.cout * 9,
-                                  flops=2.0 * 36 * tp * spec.cin * cp, e0=e0, e1=e1))
+                                  flops=2.0 * 36 * tp * spec.cin * cp,
+                                  flops_unpadded=2.0 * 36 * N * ((h + 3) // 4) * ((w + 3) // 4) * spec.cin * spec.cout, e0=e0, e1=e1))
         _lib.check(L.ssdhip_winograd4_output_head(_lib.ptr(Mo), _lib.ptr(bias), out_ptr, out_batch_stride, N, h, w, spec.cout, cp, tp, st),
                    f'winograd4_output_head {spec.name}')
 
@@ -515,7 +540,7 @@ class Engine:
 
     # ------------------------------------------------------------------------------------------------ streams
     def _note_reader(self, stage, event):
-        if event is not None and not self.single_stream and self.tail_start > 0:
+        if event is not None and not self.single_stream and self.tail_start > 0 and not self._phased:
             self._readers.setdefault(stage, []).append(event)
 
     def _side_stream(self, dev, which=0):
@@ -532,9 +557,9 @@ class Engine:
         """`with fork.side():` enqueues on the side stream after everything the main stream has enqueued so far;
         `fork.join()` makes the main stream wait for the side stream.  No-op object when single_stream is set."""
 
-        def __init__(self, engine, dev, which=0):
+        def __init__(self, engine, dev, which=0, enabled=True):
             self.main = torch.cuda.current_stream(dev)
-            self.side_stream = None if engine.single_stream else engine._side_stream(dev, which)
+            self.side_stream = None if (engine.single_stream or not enabled) else engine._side_stream(dev, which)
 
         def side(self, after=None):
             """after: the stream whose queue the side work must follow (default: the main stream)."""
@@ -556,35 +581,51 @@ class Engine:
                 self.main.wait_event(event)
 
     # ------------------------------------------------------------------------------------------------ forward
-    def forward(self, x, save, ready_event=None):
-        _lib.require_gpu(x)
-        if x.dim() != 4 or x.shape[1] != 3:
-            raise ValueError(f'expected (N, 3, H, W) input, got {tuple(x.shape)}')
-        x_in = x
-        x = _lib.f32c(x)
-        if x is not x_in:
-            ready_event = None      # a contiguous fp32 copy was just made on the caller's stream: its completion is what counts
-        N, _, H, W = x.shape
-        dev = x.device
-        b = self._buffers(N, H, W, dev)
+    def forward(self, x, save, ready_event=None, phase='all', parity=0):
+        """phase 'all' (default): the whole forward.  'backbone' / 'tail' (graph_step.py): the frozen stages alone, everything on the
+        current stream, leaving their hand-over buffers of `parity` for a later 'tail' call (x is None there), which runs the detector
+        heads, the trainable stages and returns the outputs.  Same launches in the same per-stream order as 'all'."""
+        if phase not in ('all', 'backbone', 'tail'):
+            raise ValueError(f'unknown phase {phase!r}')
+        if phase != 'all' and not (0 < self.tail_start < len(self.stages)) or (phase != 'all' and self.headless):
+            raise RuntimeError('phased execution needs a frozen backbone under a trainable tail with detector heads')
+        if phase == 'tail':
+            ctx = self._bb_ctx.get(parity)
+            if ctx is None:
+                raise RuntimeError(f"forward(phase='tail', parity={parity}) without a backbone pass of that parity")
+            b, N, H, W, dev = ctx['b'], ctx['N'], ctx['H'], ctx['W'], ctx['dev']
+            training, self.bf16 = ctx['training'], ctx['bf16']
+        else:
+            _lib.require_gpu(x)
+            if x.dim() != 4 or x.shape[1] != 3:
+                raise ValueError(f'expected (N, 3, H, W) input, got {tuple(x.shape)}')
+            x_in = x
+            x = _lib.f32c(x)
+            if x is not x_in:
+                ready_event = None      # a contiguous fp32 copy was just made on the caller's stream: its completion is what counts
+            N, _, H, W = x.shape
+            dev = x.device
+            b = self._buffers(N, H, W, dev)
+            training = self.m.training
+            self.bf16 = self.m.compute_dtype == 'bf16'
         geo = b['geo']
-        training = self.m.training
-        self.bf16 = self.m.compute_dtype == 'bf16'
-        out = torch.empty(N, b['P'], self.row, device=dev, dtype=torch.float32)
+        shared = self.shared_stages() if parity else ()
+        out = torch.empty(N, b['P'], self.row, device=dev, dtype=torch.float32) if phase != 'backbone' else None
         acts = []            # per stage: (z, xform) read by its head, (tensor, xform) read by the next conv
         nbt = []
-        fork = self._Fork(self, dev)
+        fork = self._Fork(self, dev, enabled=phase != 'backbone')
         main = fork.main
         # The frozen backbone depends on the images only, so it gets its own stream: the backbone of step i+1 starts as soon as
         # its images are there, i.e. next to the tail forward, the tail backward and the optimizer of step i (small, latency-bound
         # launches that cannot fill the chip).  Only two backbone outputs have consumers outside the backbone stream -- the inputs
         # of det_4_3 and of conv_6_1 (forward and weight gradient): those stages wait for the events their readers leave in _readers.
-        bb = None if (self.single_stream or self.tail_start == 0) else self._side_stream(dev, which=2)
+        bb = None if (self.single_stream or self.tail_start == 0 or phase != 'all') else self._side_stream(dev, which=2)
         if self._cus is None:
             self._cus = int(self.lib.ssdhip_cu_count())
         if self._wf_blocks_env is None:
             # 7/8 of the CUs (224 of 256 on an MI355X), a multiple of 32 so that every XCD gets whole channel-tile groups
-            self._wf_blocks = max(32, self._cus * 7 // 8 // 32 * 32) if (bb is not None and self.tail_start < len(self.stages)) else 0
+            beside_tail = (bb is not None or (phase != 'all' and not self.single_stream)) and self.tail_start < len(self.stages)
+            self._wf_blocks = max(32, self._cus * 7 // 8 // 32 * 32) if beside_tail else 0
         entry = main.record_event() if fork.side_stream is not None else None
         if fork.side_stream is not None:
             fork.side_stream.wait_event(entry)               # `out` may reuse memory that step i's loss kernels still read
@@ -593,7 +634,7 @@ class Engine:
             # stream, i.e. not behind the previous step's backward and optimizer; without it, it waits for everything enqueued.
             bb.wait_event(ready_event if ready_event is not None else entry)
             x.record_stream(bb)                              # the allocator must not recycle x while the backbone stream reads it
-        if save and self.tail_start > 0:
+        if save and self.tail_start > 0 and phase != 'backbone':
             # the optimizer just changed every trainable weight: repack them (forward + data-gradient layouts, Winograd U) on the
             # side stream while the frozen backbone runs; the later _pack / _wino_weights calls find their keys current
             with fork.side():
@@ -612,21 +653,34 @@ class Engine:
             prepacked = fork.mark()
         else:
             prepacked = None
-        with (torch.cuda.stream(bb) if bb is not None else contextlib.nullcontext()):
-            _lib.check(self.lib.ssdhip_normalize_nchw_to_nhwc4(_lib.ptr(x), _lib.ptr(b['x4']), N, H, W, _lib.stream()), 'normalize')
+        if phase != 'tail':
+            with (torch.cuda.stream(bb) if bb is not None else contextlib.nullcontext()):
+                _lib.check(self.lib.ssdhip_normalize_nchw_to_nhwc4(_lib.ptr(x), _lib.ptr(b['x4']), N, H, W, _lib.stream()), 'normalize')
         cur, cur_xs = b['x4'], None
         for i, (s, g) in enumerate(zip(self.stages, geo)):
             c = s.conv
             bnm = self._feat[s.bn_name]
             on_bb = bb is not None and i < self.tail_start
+            if phase == 'backbone' and i >= self.tail_start:
+                break
+            if phase == 'tail' and i < self.tail_start:
+                # the backbone pass of this parity left z / BN state / the next layer's input: only the detector head runs here
+                acts.append(ctx['acts'][i])
+                cur, cur_xs = ctx['acts'][i][2], ctx['acts'][i][3]
+                if i == self.tail_start - 1:
+                    cur, cur_xs = ctx['cur'], ctx['cur_xs']
+                if s.head is not None:
+                    self._launch_head(i, s, g, b, acts[i][0], acts[i][1], out, N, fork, None)
+                continue
             if i == self.tail_start:
                 if bb is not None:
                     main.wait_event(bb.record_event())       # backbone done: the tail continues on the caller's stream
                 fork.wait(prepacked)
             ws = b['ws'][0 if i < self.tail_start else 1]
-            z = b['z'][i]
+            alt = i in shared              # parity 1: this stage's hand-over buffers are the second copies
+            z = b['z'][i] if not alt else self._alt(b, 'z', i, b['z'][i])
             M = N * g['ho'] * g['wo']
-            bst = self._bn_state(s.bn_name, c.cout, dev)
+            bst = self._bn_state(s.bn_name, c.cout, dev, 1 if alt else 0)
             with (torch.cuda.stream(bb) if on_bb else contextlib.nullcontext()):
                 if on_bb:
                     for ev in self._readers.pop(i, ()):      # last step's readers of this stage's output / BN state
@@ -742,7 +796,7 @@ class Engine:
                 if training and rows * c.cout * 2 > ws['partial'].numel():
                     # the kernels cannot check this themselves; an undersized table once corrupted its neighbours silently
                     raise RuntimeError(f'{c.name}: {rows} BatchNorm partial rows do not fit the workspace ({ws["partial"].numel()} floats)')
-                if bb is not None and i == self.tail_start:
+                if bb is not None and i == self.tail_start and not self._phased:
                     self._note_reader(i - 1, main.record_event())     # the backbone's last activation is consumed
                 if training:
                     track = bnm.track_running_stats and bnm.running_mean is not None
@@ -766,18 +820,20 @@ class Engine:
                         cn, gn = self.stages[i + 1].conv, geo[i + 1]
                         abf = torch.zeros(self.lib.ssdhip_conv_bf16_act_bytes(N, gn['hi'], gn['wi'], cn.cin) // 2, device=dev, dtype=torch.bfloat16)
                         b['abf'][i + 1] = abf
+                    if alt and i + 1 == self.tail_start:
+                        abf = self._alt(b, 'abf', i + 1, abf)        # zero halo like the first copy; the interior is rewritten every pass
                     _lib.check(self.lib.ssdhip_bn_relu_to_bf16(_lib.ptr(z), int(z_bf16), _lib.ptr(bst['scale']), _lib.ptr(bst['shift']), _lib.ptr(abf),
                                                                N, g['ho'], g['wo'], c.cout, int(s.pool_pad is not None), s.pool_pad or 0, st),
                                f'bn_relu_to_bf16 after {c.name}')
                     cur, cur_xs = abf, None
                 elif pool_fused:
-                    pooled = b['pooled'][i]
+                    pooled = b['pooled'][i] if not alt else self._alt(b, 'pooled', i, b['pooled'][i])
                     zmm = b['zmm'][i]
                     _lib.check(self.lib.ssdhip_bn_relu_select(_lib.ptr(zmm[0]), _lib.ptr(zmm[1]), _lib.ptr(bst['scale']), _lib.ptr(bst['shift']),
                                                               _lib.ptr(pooled), N * g['ha'] * g['wa'], c.cout, st), f'pool (select) after {c.name}')
                     cur, cur_xs = pooled, None
                 elif s.pool_pad is not None:
-                    pooled = b['pooled'][i]
+                    pooled = b['pooled'][i] if not alt else self._alt(b, 'pooled', i, b['pooled'][i])
                     _lib.check(self.lib.ssdhip_bn_relu_pool(_lib.ptr(z), _lib.ptr(bst['scale']), _lib.ptr(bst['shift']), _lib.ptr(pooled),
                                                             N, g['ho'], g['wo'], c.cout, 1, s.pool_pad, st), f'pool after {c.name}')
                     cur, cur_xs = pooled, None
@@ -787,20 +843,15 @@ class Engine:
                 # FORWARD took the haloed bf16 copy and is trainable (conv_6_1), its weight gradient still reads z and this BN state
                 # (_patch_ok admits that case only without a pool in between)
                 acts.append((z, act_xs, cur, cur_xs) if cur_xs is not None or cur.dtype == torch.float32 else (z, act_xs, z, act_xs))
-                if s.head is not None:
-                    off = b['head_off'][s.head_index]
-                    with fork.side(after=bb if on_bb else None):   # needs z and this stage's BN scale/shift only; writes its own rows of `out`
-                        if i in b['head_f4'] and not self.bf16:
-                            self._head_winograd4(s.head, z, act_xs, b['head_v'][i], b, ctypes.c_void_p(out.data_ptr() + off * self.row * 4),
-                                                 b['P'] * self.row, N, g['ho'], g['wo'])
-                        elif i in b['head_v'] and not self.bf16:
-                            self._head_winograd(s.head, z, act_xs, b['head_v'][i], b, ctypes.c_void_p(out.data_ptr() + off * self.row * 4),
-                                                b['P'] * self.row, N, g['ho'], g['wo'])
-                        else:
-                            self._conv(s.head, z, act_xs, out.data_ptr() + off * self.row * 4, b['P'] * self.row, N, g['ho'], g['wo'],
-                                       g['ho'], g['wo'], None)
+                if s.head is not None and phase != 'backbone':
+                    self._launch_head(i, s, g, b, z, act_xs, out, N, fork, bb if on_bb else None)
                     if on_bb:
                         self._note_reader(i, fork.mark())
+        if phase == 'backbone':
+            if nbt:
+                torch._foreach_add_(nbt, 1)
+            self._bb_ctx[parity] = dict(b=b, N=N, H=H, W=W, dev=dev, acts=acts, cur=cur, cur_xs=cur_xs, training=training, bf16=self.bf16)
+            return None
         if bb is not None and self.tail_start >= len(self.stages):
             main.wait_event(bb.record_event())       # everything frozen (VGG16 transfer learning): the whole stack ran on the backbone stream
         fork.join()
@@ -812,6 +863,20 @@ class Engine:
                 raise RuntimeError('a head-less feature stack must end in a pool (its BN.ReLU is applied there)')
             return cur          # (N, h, w, C) NHWC: the pooled last activation (a workspace tensor: consume it before the next forward)
         return out
+
+    def _launch_head(self, i, s, g, b, z, act_xs, out, N, fork, after):
+        """Detector head of stage i on the side stream: needs z and this stage's BN scale / shift only; writes its own rows of `out`."""
+        off = b['head_off'][s.head_index]
+        with fork.side(after=after):
+            if i in b['head_f4'] and not self.bf16:
+                self._head_winograd4(s.head, z, act_xs, b['head_v'][i], b, ctypes.c_void_p(out.data_ptr() + off * self.row * 4),
+                                     b['P'] * self.row, N, g['ho'], g['wo'])
+            elif i in b['head_v'] and not self.bf16:
+                self._head_winograd(s.head, z, act_xs, b['head_v'][i], b, ctypes.c_void_p(out.data_ptr() + off * self.row * 4),
+                                    b['P'] * self.row, N, g['ho'], g['wo'])
+            else:
+                self._conv(s.head, z, act_xs, out.data_ptr() + off * self.row * 4, b['P'] * self.row, N, g['ho'], g['wo'],
+                           g['ho'], g['wo'], None)
 
     # ------------------------------------------------------------------------------------------------ backward
     def grad_layout(self):
@@ -1049,7 +1114,8 @@ class Engine:
                 x, xs = acts[i][0], acts[i][1]
                 with fork.side():
                     self._wgrad(s.head, x, xs, bw['dyh'][i], views, bw, N, g['ho'], g['wo'], g['ho'], g['wo'], None if self.bf16 else b['head_v'].get(i))
-                self._note_reader(i, fork.mark())    # the next backbone pass may overwrite z[i] / its BN state after this
+                if not self._phased:
+                    self._note_reader(i, fork.mark())    # the next backbone pass may overwrite z[i] / its BN state after this
         last = len(self.stages) - 1
         for i in range(last, self.tail_start - 1, -1):
             s, g = self.stages[i], geo[i]
@@ -1087,7 +1153,7 @@ class Engine:
                 self.dist_hook.start(flat, cut, flat.numel())
             with fork.side():
                 self._wgrad(c, xin, xin_xs, dz, views, bw, N, g['hi'], g['wi'], g['ho'], g['wo'])
-            if i == self.tail_start and i > 0:
+            if i == self.tail_start and i > 0 and not self._phased:
                 self._note_reader(i - 1, fork.mark())   # conv_6_1's weight gradient reads the backbone's last activation
             if i > self.tail_start:
                 prev, gp = self.stages[i - 1], geo[i - 1]

@@ -264,8 +264,9 @@ def conv2d_dgrad(dy, w_oihw, in_hw, stride=1, pad=0, accumulate_into=None, tile=
     return dx
 
 
-def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, in_scale=None, in_shift=None, want_bias=True, winograd=False, bf16=False):
+def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, in_scale=None, in_shift=None, want_bias=True, winograd=False, bf16=False, wino_v=None):
     """x (N,Hi,Wi,Cin), dy (N,Ho,Wo,dy_row>=Cout) -> (dW OIHW, db or None).  winograd=True: F(2x2,3x3) path (3x3/s1/p1); winograd=4: F(4x4,3x3).
+    wino_v (Winograd paths): the forward's input transform of x (planes padded to 128 rows), reused instead of recomputed.
     bf16 (direct path only): operands rounded to bf16 at staging, bf16 MFMA with fp32 accumulate, fp32 result."""
     _lib.require_gpu(x, dy)
     lib = _lib.load()
@@ -284,6 +285,9 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, in_scale=None, in_shift=None, 
     p.R, p.S, p.stride, p.pad, p.dy_row = k, k, stride, pad, row
     if bf16 and winograd:
         raise ValueError('conv2d_wgrad: the bf16 weight gradient is the direct kernel (no Winograd form)')
+    if wino_v is not None and not winograd:
+        raise ValueError('conv2d_wgrad: wino_v only applies to the Winograd forms')
+    p.wino_v = wino_v.data_ptr() if wino_v is not None else None
     p.compute = int(bf16)
     if winograd == 4 and not isinstance(winograd, bool):      # F(4x4,3x3)
         fn_ws, fn = lib.ssdhip_conv2d_wgrad_winograd4_ws_bytes, lib.ssdhip_conv2d_wgrad_winograd4
@@ -393,9 +397,12 @@ WINOGRAD4_AT = [['1', '1', '1', '1', '1', '0'], ['0', '3/2', '-3/2', '2/3', '-2/
                 ['0', '27/8', '-27/8', '8/27', '-8/27', '1']]
 
 
-def conv3x3_winograd4(x, w_oihw, bias=None, in_scale=None, in_shift=None, want_stats=False, tile=0):
+def conv3x3_winograd4(x, w_oihw, bias=None, in_scale=None, in_shift=None, want_stats=False, tile=0, return_v=False):
     """3x3 / stride 1 / pad 1 convolution through the Winograd F(4x4,3x3) passes (csrc/winograd4.hip).  x (N,H,W,Cin) NHWC,
-    Cin % 32 == 0.  Returns (z (N,H,W,Cout), stats (rows,Cout,2) or None)."""
+    Cin % 32 == 0.  Returns (z (N,H,W,Cout), stats (rows,Cout,2) or None) (+ the input transform V with return_v: what the engine
+    hands to the heads' weight gradient).  The padding rows T..Tp of every plane are filled with NaN here: the engine feeds the GEMM
+    uninitialised memory there (torch.empty workspaces), which is only safe because no pass reads a product of a padding row -- a
+    result that stays finite under this poison proves it."""
     _lib.require_gpu(x, w_oihw)
     lib = _lib.load()
     N, H, W, C = x.shape
@@ -415,7 +422,7 @@ def conv3x3_winograd4(x, w_oihw, bias=None, in_scale=None, in_shift=None, want_s
     st = _lib.stream()
     _lib.check(lib.ssdhip_winograd4_weight(_lib.ptr(_lib.f32c(w_oihw)), _lib.ptr(U), cout, cin, rows_pad, C, st), 'winograd4_weight')
     if Tp > T:
-        V.view(36, Tp, C)[:, T:].zero_()          # padding rows of every plane feed the GEMM (their products are never read back)
+        V.view(36, Tp, C)[:, T:].fill_(float('nan'))     # padding rows of every plane feed the GEMM; their products must never be read back
     _lib.check(lib.ssdhip_winograd4_input(_lib.ptr(x), _lib.ptr(in_scale), _lib.ptr(in_shift), _lib.ptr(V), N, H, W, C, Tp, st), 'winograd4_input')
     p = _lib.ConvParams()
     p.x, p.w, p.y, p.y_batch_stride = V.data_ptr(), U.data_ptr(), Mo.data_ptr(), Tp * cout
@@ -427,7 +434,7 @@ def conv3x3_winograd4(x, w_oihw, bias=None, in_scale=None, in_shift=None, want_s
     stats = torch.empty(rows, cout, 2, device=dev, dtype=torch.float32) if want_stats else None
     got = _lib.check(lib.ssdhip_winograd4_output(_lib.ptr(Mo), _lib.ptr(bias), _lib.ptr(z), _lib.ptr(stats), 0, N, H, W, cout, Tp, st), 'winograd4_output')
     assert got == rows
-    return z, stats
+    return (z, stats, V) if return_v else (z, stats)
 
 
 def conv3x3_dgrad_winograd4(dy, w_oihw, accumulate_into=None):
@@ -445,7 +452,7 @@ def conv3x3_dgrad_winograd4(dy, w_oihw, accumulate_into=None):
     rows = _rup(cin, 128)
     dev = dy.device
     U = torch.empty(36 * rows * KP, device=dev, dtype=torch.float32)
-    V = torch.zeros(36 * Tp * KP, device=dev, dtype=torch.float32)
+    V = torch.full((36 * Tp * KP,), float('nan'), device=dev, dtype=torch.float32)     # rows t < T are overwritten, the padding rows stay poisoned
     Mo = torch.empty(36 * Tp * cin, device=dev, dtype=torch.float32)
     dx = accumulate_into if accumulate_into is not None else torch.empty(N, H, W, cin, device=dev, dtype=torch.float32)
     st = _lib.stream()

@@ -54,7 +54,7 @@ class FusedAdam(torch.optim.Optimizer):
         # the device step counter always restarts from the host-side per-parameter step (kept current by step(), replaced by
         # load_state_dict), like torch.optim.Adam; one shared counter: the tensors of a group step together
         step0 = int(max(int(self.state[p].get('step', 0)) for p in params))
-        plan = dict(key=key, n_blocks=len(blocks),
+        plan = dict(key=key, n_blocks=len(blocks), gi=gi,
                     table=torch.tensor(rows, dtype=torch.int64, device=dev),
                     sizes=torch.tensor(sizes, dtype=torch.int64, device=dev),
                     blockmap=torch.tensor(blocks, dtype=torch.int32, device=dev),
@@ -66,12 +66,11 @@ class FusedAdam(torch.optim.Optimizer):
         return plan
 
     @torch.no_grad()
-    def step(self, closure=None):
-        loss = None
-        if closure is not None:
-            with torch.enable_grad():
-                loss = closure()
-        lib = _lib.load()
+    def prepare(self):
+        """Host side of a step, safe OUTSIDE a graph capture only: launch plans exist (device pointer tables are uploaded when a
+        tensor was replaced) and the device copy of lr / weight_decay / grad_scale is current (lr scheduler, train.py:98,154).
+        Returns [(plan, params)] for `enqueue`."""
+        work = []
         for gi, group in enumerate(self.param_groups):
             params = [p for p in group['params'] if p.grad is not None]
             if not params:
@@ -79,13 +78,38 @@ class FusedAdam(torch.optim.Optimizer):
             _lib.require_gpu(*params)
             plan = self._plan(gi, group, params)
             host = (group['lr'], group['weight_decay'], group['grad_scale'])
-            if host != plan['host']:            # lr scheduler (train.py:98,154) or user changed a hyper-parameter
+            if host != plan['host']:
                 plan['hyper'][0] = group['lr']; plan['hyper'][4] = group['weight_decay']; plan['hyper'][7] = group['grad_scale']
                 plan['host'] = host
-            st = _lib.stream()
+            work.append((plan, params))
+        return work
+
+    def refresh(self, work):
+        """The per-step part of `prepare` for a caller that holds `work` across steps (a captured graph): hyper-parameters only.
+        Raises when the plan it was given is no longer the optimizer's (state replaced: load_state_dict / invalidate)."""
+        for plan, _ in work:
+            if self._plans.get(plan['gi']) is not plan:
+                raise RuntimeError('FusedAdam: the launch plan held by a captured step is stale (optimizer state was replaced)')
+            group = self.param_groups[plan['gi']]
+            host = (group['lr'], group['weight_decay'], group['grad_scale'])
+            if host != plan['host']:
+                plan['hyper'][0] = group['lr']; plan['hyper'][4] = group['weight_decay']; plan['hyper'][7] = group['grad_scale']
+                plan['host'] = host
+
+    @staticmethod
+    def enqueue(work):
+        """Device side: two launches per group (step counter / bias corrections, then the update of every tensor); nothing else,
+        so a HIP graph may hold it (graph_step.py)."""
+        lib = _lib.load()
+        st = _lib.stream()
+        for plan, _ in work:
             _lib.check(lib.ssdhip_adam_tick(_lib.ptr(plan['step']), _lib.ptr(plan['hyper']), st), 'adam_tick')
             _lib.check(lib.ssdhip_adam_multi_tensor(_lib.ptr(plan['table']), _lib.ptr(plan['sizes']), _lib.ptr(plan['blockmap']),
                                                     plan['n_blocks'], _CHUNK, _lib.ptr(plan['hyper']), st), 'adam')
+
+    def committed(self, work):
+        """Host bookkeeping after `enqueue` ran (or after the replay of a graph that holds it)."""
+        for _, params in work:
             for p in params:
                 self.state[p]['step'] += 1
             # the kernel wrote through raw pointers: tell torch (and every cache keyed on `_version`, e.g. the engine's packed and
@@ -93,4 +117,14 @@ class FusedAdam(torch.optim.Optimizer):
             torch.autograd.graph.increment_version(params)
         if self._on_step is not None:
             self._on_step()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        work = self.prepare()
+        self.enqueue(work)
+        self.committed(work)
         return loss

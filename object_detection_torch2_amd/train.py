@@ -13,6 +13,8 @@ all-reduced with RCCL.
 """
 import argparse
 import json
+import os
+import sys
 import time
 from pathlib import Path
 
@@ -25,10 +27,13 @@ from .model import SSD
 from .optim import FusedAdam
 
 
-def build_model(device, world, weights_path=None, weights_path_vgg16=None, num_classes=20 + 1, imsize=300):
+def build_model(device, world, weights_path=None, weights_path_vgg16=None, num_classes=20 + 1, imsize=300, dtype='fp32'):
     """train.py:76-83 + the data-parallel start condition: every rank holds rank 0's parameters and buffers.  SSD() draws its
-    initial weights from the process's own (unseeded) RNG, so without the broadcast N ranks would train N different models."""
+    initial weights from the process's own (unseeded) RNG, so without the broadcast N ranks would train N different models.
+    imsize 300 / 512 selects the prior layout (BASELINE configs[4]), dtype 'fp32' / 'bf16' the arithmetic of the convolutions
+    (configs[3]: bf16 forward / backward on fp32 master parameters)."""
     net = SSD(num_classes=num_classes, weights_path=weights_path, weights_path_vgg16=weights_path_vgg16, imsize=imsize)
+    net.set_compute_dtype(dtype)
     net.to(device)
     if world > 1:
         parallel.broadcast_module(net)
@@ -52,7 +57,7 @@ def end_of_epoch(net, rank, world, epoch, local_loss, min_loss, lr, weights_path
     return loss, min_loss
 
 
-def main():
+def main(argv=None):
     parser = argparse.ArgumentParser()
     parser.add_argument('--purpose', type=str, default='detection')
     parser.add_argument('--imsize', type=int, default=300)
@@ -69,14 +74,31 @@ def main():
     parser.add_argument('--steps_per_epoch', type=int, default=20, help='synthetic source only')
     parser.add_argument('--data_dirs', type=str, nargs='*', default=None, help='VOC roots, e.g. /work/data/VOCdevkit/VOC2007 (train.py:43)')
     parser.add_argument('--data_list', type=str, default='trainval.txt')
-    args = parser.parse_args()
+    parser.add_argument('--dtype', type=str, default='fp32', choices=('fp32', 'bf16'),
+                        help='arithmetic of the convolutions: fp32 (the reference) or bf16 forward / backward on fp32 master parameters')
+    parser.add_argument('--device-count', dest='device_count', type=int, default=None,
+                        help='GPUs of this node to train on: without a launcher the script starts one rank per GPU itself '
+                             '(under torch.distributed.run the launcher decides and this must match WORLD_SIZE)')
+    parser.add_argument('--seed', type=int, default=None, help='seed of the initial weights (the reference draws them unseeded)')
+    parser.add_argument('--graph_max_gt', type=int, default=64, help='--graph: ground-truth rows per image the captured step is built for')
+    parser.add_argument('--graph', action='store_true',
+                        help='replay the train step as one HIP graph (tail of step i beside the frozen backbone of step i+1)')
+    args = parser.parse_args(argv)
     if args.purpose not in ('detection', 'classification'):
         raise SystemExit(f'--purpose must be detection or classification, got {args.purpose!r}')
     classify = args.purpose == 'classification'
+    if args.device_count is not None and args.device_count > 1 and 'WORLD_SIZE' not in os.environ:
+        # no launcher: start one fresh rank process per GPU from here, before this process touches the GPU (it never does)
+        raise SystemExit(parallel.launch_local_ranks(args.device_count, [sys.executable, '-m', 'object_detection_torch2_amd.train']
+                                                     + (sys.argv[1:] if argv is None else list(argv))))
 
     rank, world, local = parallel.init_from_env()
+    if args.device_count is not None and args.device_count != world:
+        raise SystemExit(f'--device-count {args.device_count} but WORLD_SIZE={world}')
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
+    if args.seed is not None:
+        torch.manual_seed(args.seed)
     weights_path = Path(args.result_dir) / args.purpose / args.weights
     params_path = Path(args.result_dir) / args.purpose / args.params
 
@@ -91,7 +113,8 @@ def main():
             net.dropout_seed = rank          # one seed on every rank would drop the same units in every shard of the global batch (correlated masks)
         defaults = None
     else:
-        net = build_model(device, world, weights_path, Path(args.result_dir) / 'classification' / args.weights)
+        net = build_model(device, world, weights_path, Path(args.result_dir) / 'classification' / args.weights, imsize=args.imsize,
+                          dtype=args.dtype)
         defaults = net.default_bboxes.to(device)
 
     if params_path.exists():
@@ -133,6 +156,7 @@ def main():
             else:
                 yield ims, torch.from_numpy(synth.targets(seed, args.batch_size * world)[lo:hi]).to(device)
 
+    runner = None
     for epoch in range(1 + start_epoch, args.epochs + start_epoch + 1):
         running = torch.zeros((), device=device)
         t0 = time.perf_counter()
@@ -146,9 +170,26 @@ def main():
             return None if item is None else (item[0], item[1], torch.cuda.current_stream().record_event())
 
         cur = fetch()
+        graphed = args.graph and not classify
+        if graphed and cur is not None and runner is None:
+            # one captured step for the whole run: batch shape of the first batch, ground truth padded to --graph_max_gt rows (zero rows
+            # never match, ssd.py:231-250, so padding changes nothing); a ragged last batch falls back to the eager step below
+            from .graph_step import GraphedTrainStep
+            runner = GraphedTrainStep(net, optimizer, defaults, cur[0].shape, (cur[0].shape[0], max(args.graph_max_gt, cur[1].shape[1]), cur[1].shape[2]))
+        fits = lambda item: item is not None and tuple(item[0].shape) == tuple(runner._x.shape) and item[1].shape[1] <= runner.G
+        if graphed and fits(cur):
+            runner.feed(cur[0], cur[2])
         while cur is not None:
             ims, gts, ready = cur
             n_steps += 1
+            if graphed and fits(cur):
+                cur = fetch()
+                if fits(cur):
+                    runner.feed(cur[0], cur[2])       # backbone of the next batch on its own stream, beside this batch's tail
+                running += runner.step(gts)
+                if not fits(cur):
+                    runner.drain()                    # end of the epoch or an eager step next
+                continue
             optimizer.zero_grad()
             if classify:
                 outputs = net(ims)
@@ -160,6 +201,8 @@ def main():
             loss.backward()
             optimizer.step()
             running += loss.detach()
+            if graphed and fits(cur):
+                runner.feed(cur[0], cur[2])
         local_loss = running.item() / max(n_steps, 1)
         dt = time.perf_counter() - t0
         # every rank: same global loss, same branch (the checkpoint branch holds a collective)

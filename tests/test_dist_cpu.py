@@ -47,7 +47,27 @@ def _worker(rank, world, port, q):
     parallel.sync_bn_stats(net)
     rm = net.features['bn_6_1'].running_mean
     ok_bn = torch.allclose(rm, torch.full_like(rm, (world - 1) / 2))
-    q.put((rank, lo, hi, ranges, ok_sum, ok_avg, ok_bn))
+    # selectable exchange: reduce-scatter + all-gather in place, odd sizes (remainder path), bf16 payload
+    ok_modes = True
+    for mode, payload in (('rs_ag', 'fp32'), ('allreduce', 'bf16'), ('rs_ag', 'bf16')):
+        h = parallel.GradAllReduce(n_buckets=3, mode=mode, payload=payload)
+        v = torch.arange(n, dtype=torch.float32).remainder(251.0) * (rank + 1)       # integers <= 250 * 3: exact in bf16 sums? (<= 256 * 3)
+        h.start(v, cut, n)
+        h.finish(v)
+        want = torch.arange(n, dtype=torch.float32).remainder(251.0) * sum(range(1, world + 1))
+        if payload == 'fp32':
+            ok_modes &= torch.equal(v, want)
+        else:
+            ok_modes &= bool(((v - want).abs() <= want.abs() * 2 ** -7 + 1e-6).all())    # three bf16 roundings of 8-bit mantissas
+        d = h.describe()
+        ok_modes &= d['ranks_seen'] == world and d['mode'] == mode and d['payload'] == payload and len(d['collectives_last_step']) >= 3
+        ok_modes &= sum(e[1] for e in d['collectives_last_step']) == n                # every element travelled exactly once
+    try:
+        parallel.GradAllReduce(mode='ring')
+        ok_modes = False
+    except ValueError:
+        pass
+    q.put((rank, lo, hi, ranges, ok_sum, ok_avg, ok_bn, ok_modes))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -68,6 +88,7 @@ def test_gloo_world2_allreduce_and_sharding():
         ranges = r[3]
         assert ranges[0][0] == 0 and ranges[-1][1] == 100003 and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
         assert all(lo % 4 == 0 for lo, _ in ranges)                   # 16-byte aligned buckets
+        assert r[7], 'rs_ag / bf16 exchange modes'
         assert r[4] and r[5] and r[6]
 
 

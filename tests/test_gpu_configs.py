@@ -1,0 +1,172 @@
+"""GPU: the BASELINE.json configs at their PER-GPU size, on the HIP path, against the CPU oracle.
+
+configs[3] = SSD300 bf16 forward / backward + fp32 master at batch 32 per GPU; configs[4] = SSD512 bf16 at batch 16 per GPU (their
+8-GPU forms shard these by image, tests/test_dist_cpu.py / test_gpu_dist.py).  The reference is fp32 only, so what pins a bf16 run
+is the fp32 oracle of the same network at bf16-sized bounds (the bounds of tests/test_gpu_bf16.py, taken at batch 2 / 4) plus the
+size-independent properties of tests/test_gpu_model.py: bit-identical replay, batch-permutation equivariance, a finite Adam step.
+The oracle's forward + tail backward at these sizes is a few seconds of torch CPU convolutions on the box's host cores."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _oracle_run(O, imsize, ims, tg, num_classes=21, seed=1):
+    sd = O.init_state(seed=seed, num_classes=num_classes, imsize=imsize)
+    names = O.trainable_param_names(num_classes, imsize=imsize)
+    df = O.default_bboxes(imsize)
+    for k in names:
+        sd[k].requires_grad_(True)
+    out_o = O.forward(sd, torch.from_numpy(ims), num_classes=num_classes, training=True, imsize=imsize)
+    o = out_o.detach().numpy()
+    out_o.backward(torch.from_numpy(O.loss_grad(o, tg, df)))
+    return sd, names, df, o, float(O.loss(o, tg, df))
+
+
+def _bf16_config_case(imsize, N, first_head_priors, seeds):
+    from oracle import ssd_oracle as O
+    from object_detection_torch2_amd import synth
+    from object_detection_torch2_amd.model import SSD
+    from object_detection_torch2_amd.optim import FusedAdam
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    ims, tg = synth.images(seeds[0], N, imsize), synth.targets(seeds[1], N, g_max=8)
+    sd, names, df, o, loss_ref = _oracle_run(O, imsize, ims, tg)
+    net = SSD(num_classes=21, imsize=imsize)
+    net.load_state_dict(O.init_state(seed=1, imsize=imsize))
+    net.to(DEV).set_compute_dtype('bf16')
+    opt = FusedAdam(net.train_params(), lr=1e-3, weight_decay=5e-4, on_step=net.hip_weights_changed)
+    x, t, d = torch.from_numpy(ims).to(DEV), torch.from_numpy(tg).to(DEV), torch.from_numpy(df).to(DEV)
+    P = df.shape[0]
+    # ---- size-independent properties first (they need the untouched weights): replay and permutation
+    with torch.no_grad():
+        y1 = net(x).clone()
+        y2 = net(x).clone()
+        assert torch.equal(y1, y2)                                   # no atomics, no LDS race: same bits
+        perm = torch.randperm(N, generator=torch.Generator().manual_seed(3)).to(DEV)
+        yp = net(x[perm].contiguous())
+        # train-mode BN statistics are permutation invariant up to summation order; a bf16 rounding boundary crossed by that
+        # order moves one operand by 2^-9: relative L2 (the absolute bound of the fp32 test does not apply to bf16 operands)
+        assert ((yp - y1[perm]).norm() / y1.norm()).item() < 2e-2
+    assert tuple(y1.shape) == (N, P, 25) and torch.isfinite(y1).all()
+    # ---- forward / loss / gradients vs the fp32 oracle
+    opt.zero_grad()
+    out = net(x)
+    dlt = out.detach().cpu().numpy() - o
+    rel_all = np.linalg.norm(dlt) / np.linalg.norm(o)
+    rel_head = np.linalg.norm(dlt[:, :first_head_priors]) / np.linalg.norm(o[:, :first_head_priors])
+    assert rel_all < 0.10 and rel_head < 0.05, (rel_all, rel_head)   # bounds of the batch-2 / batch-4 bf16 tests
+    loss = net.loss(out, t, d)
+    assert abs(loss.item() - loss_ref) < 0.02 * abs(loss_ref), (loss.item(), loss_ref)
+    loss.backward()
+    got = dict(net.named_train_params())
+    for k in names:
+        if not k.endswith('.weight') or '.bn_' in k:
+            continue
+        g, r = got[k].grad.cpu().double(), sd[k].grad.double()
+        assert torch.isfinite(g).all(), k
+        cos = (g * r).sum().item() / (g.norm().item() * r.norm().item())
+        big = k in ('detectors.det_4_3.weight', 'detectors.det_7_1.weight', 'features.conv_6_1.weight', 'features.conv_7_1.weight')
+        # full batch: every gradient sums over >= N positions; the large layers see bf16 noise once or twice, the late ones behind
+        # 4-10 more bf16 layers with BatchNorm over few pixels (direction bound only, as at batch 2)
+        assert cos > (0.99 if big else 0.90), (k, cos)
+        if big:
+            assert ((g - r).norm() / r.norm()).item() < 0.15, k
+    before = {k: got[k].detach().clone() for k in ('detectors.det_4_3.weight', 'features.conv_6_1.weight', 'features.bn_7_1.bias')}
+    opt.step()
+    torch.cuda.synchronize()
+    for k, v in before.items():
+        assert not torch.equal(v, got[k]) and torch.isfinite(got[k]).all() and got[k].dtype == torch.float32, k   # fp32 master moved
+        assert (got[k] - v).abs().max().item() <= 1.001e-3 * (1 + 5e-4 * v.abs().max().item()) + 1e-9, k       # |Adam step| <= lr
+    # second step runs on the updated weights (repacked images, bf16 weight copies) and lowers the loss on the same batch
+    opt.zero_grad()
+    loss2 = net.loss(net(x), t, d)
+    assert torch.isfinite(loss2) and loss2.item() < loss.item()
+    # fp32 running statistics of the frozen bf16 backbone stay those of the fp32 network within bf16 noise
+    st = net.state_dict()
+    for k in ('features.bn_4_3.running_mean', 'features.bn_7_1.running_var'):
+        a, b = st[k].cpu().double(), sd[k].detach().double()
+        assert ((a - b).norm() / b.norm()).item() < 0.05, k
+
+
+def test_config3_ssd300_bf16_batch32_vs_oracle():
+    """BASELINE configs[3], one GPU's share: SSD300, batch 32, bf16 forward / backward on fp32 master parameters."""
+    _bf16_config_case(300, 32, 5776, (100, 200))
+
+
+def test_config4_ssd512_bf16_batch16_vs_oracle():
+    """BASELINE configs[4], one GPU's share: SSD512 (24,564 priors), batch 16, bf16."""
+    _bf16_config_case(512, 16, 64 * 64 * 4, (161, 162))
+
+
+def test_config4_ssd512_fp32_batch16_vs_oracle():
+    """The fp32 form of the same shard: forward 2e-3, loss at the north-star 1e-4, detector gradients 1e-3."""
+    from oracle import ssd_oracle as O
+    from object_detection_torch2_amd import synth
+    from object_detection_torch2_amd.model import SSD
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    N = 16
+    ims, tg = synth.images(161, N, 512), synth.targets(162, N, g_max=8)
+    sd, names, df, o, loss_ref = _oracle_run(O, 512, ims, tg)
+    net = SSD(num_classes=21, imsize=512)
+    net.load_state_dict(O.init_state(seed=1, imsize=512))
+    net.to(DEV)
+    out = net(torch.from_numpy(ims).to(DEV))
+    assert np.abs(out.detach().cpu().numpy() - o).max() < 2e-3
+    loss = net.loss(out, torch.from_numpy(tg).to(DEV), torch.from_numpy(df).to(DEV))
+    assert abs(loss.item() - loss_ref) < 1e-4, (loss.item(), loss_ref)
+    loss.backward()
+    got = dict(net.named_train_params())
+    for k in names:
+        if k.startswith('detectors.'):
+            g, r = got[k].grad.cpu().double(), sd[k].grad.double()
+            assert ((g - r).norm() / r.norm()).item() < 1e-3, k
+
+
+def test_five_classes_batch32_tight_bounds():
+    """The five-class forward at a non-degenerate batch: the batch-of-two case of test_gpu_classes.py needs 4e-3 on its last 40 priors
+    (BatchNorm over 2 and 18 samples per channel amplifies backbone rounding); at batch 32 EVERY prior, the 3x3 and 1x1 maps included,
+    is held at 1e-3 and the loss at the north-star 1e-4 -- the widened small-batch bound is a BatchNorm artefact, not drift."""
+    from oracle import ssd_oracle as O
+    from object_detection_torch2_amd import synth
+    from object_detection_torch2_amd.model import SSD
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    C, N = 5, 32
+    ims, tg = synth.images(70, N), synth.targets(71, N, g_max=5, num_classes=C)
+    sd, names, df, o, loss_ref = _oracle_run(O, 300, ims, tg, num_classes=C, seed=3)
+    net = SSD(num_classes=C)
+    net.load_state_dict(O.init_state(seed=3, num_classes=C))
+    net.to(DEV)
+    out = net(torch.from_numpy(ims).to(DEV))
+    err = np.abs(out.detach().cpu().numpy() - o)
+    assert err.max() < 1e-3, (err[:, :8692].max(), err[:, 8692:].max())
+    loss = net.loss(out, torch.from_numpy(tg).to(DEV), torch.from_numpy(df).to(DEV))
+    assert abs(loss.item() - loss_ref) < 1e-4, (loss.item(), loss_ref)
+    loss.backward()
+    got = dict(net.named_train_params())
+    for k in names:
+        if k.startswith('detectors.'):
+            g, r = got[k].grad.cpu().double(), sd[k].grad.double()
+            assert ((g - r).norm() / r.norm()).item() < 1e-3, k
+
+
+def test_entry_points_reach_ssd512_and_bf16(tmp_path, capsys):
+    """train.py / inference.py / evaluate.py with `--imsize 512 --dtype bf16` (the reference's flags, train.py:15-27, plus --dtype): the
+    flags reach SSD(...) -- the checkpoint holds the 24,564-prior network (det_12_2, 189 entries) and the other two load it."""
+    from object_detection_torch2_amd import evaluate, inference, train
+    res = tmp_path / 'result'
+    torch.manual_seed(5)
+    train.main(['--imsize', '512', '--dtype', 'bf16', '--batch_size', '2', '--epochs', '1', '--steps_per_epoch', '2', '--result_dir', str(res)])
+    out = capsys.readouterr().out
+    assert 'Finished Training' in out
+    sd = torch.load(res / 'detection' / 'weights.pth', map_location='cpu', weights_only=True)
+    assert len(sd) == 189 and 'detectors.det_12_2.weight' in sd and all(torch.isfinite(v.float()).all() for v in sd.values())
+    inference.main(['--imsize', '512', '--dtype', 'bf16', '--batch_size', '2', '--batches', '1', '--result_dir', str(res)])
+    out = capsys.readouterr().out
+    assert 'weights loaded.' in out and 'Finished Inference' in out and 'image 2:' in out
+    evaluate.main(['--imsize', '512', '--dtype', 'bf16', '--batch_size', '2', '--batches', '1', '--result_dir', str(res)])
+    out = capsys.readouterr().out
+    assert 'weights loaded.' in out and 'Finished Evaluate' in out
+    with pytest.raises(SystemExit):
+        train.main(['--dtype', 'fp16'])

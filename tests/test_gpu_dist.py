@@ -68,3 +68,23 @@ def test_bench_self_launch_two_ranks_on_one_gpu(dtype):
     assert line['n_gpus'] == 2 and line['ranks'] == 2 and line['config']['global_batch'] == 8 and line['scaling'] == 'weak'
     assert line['value'] > 0 and line['comm_ms_per_step'] > 0 and 'comm_exposed_ms_per_step' in line
     assert line['roofline']['bound'] == 'mfma' and line['dtype'] == ('bf16' if dtype == 'bf16' else 'f32')
+
+
+@pytest.mark.parametrize('graph', [False, True])
+def test_train_device_count_self_launch_two_ranks_on_one_gpu(tmp_path, graph):
+    """`train.py --device-count 2` without a launcher: the script starts its two ranks itself (gloo, both on the box's one GPU).
+    With --graph the captured tail is cut at the two all-reduce points and REAL two-rank collectives run between the segments; the
+    epoch losses must equal the eager data-parallel run's."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(SSD_DIST_BACKEND='gloo', SSD_FORCE_DEVICE='0', PYTHONPATH=ROOT + os.pathsep + env.get('PYTHONPATH', ''))
+    outs = []
+    for mode in ([], ['--graph']) if graph else ([],):
+        r = subprocess.run([sys.executable, '-m', 'object_detection_torch2_amd.train', '--device-count', '2', '--batch_size', '2', '--epochs', '2',
+                            '--steps_per_epoch', '3', '--seed', '7', '--result_dir', str(tmp_path / ('g' if mode else 'e'))] + mode,
+                           env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        assert 'Finished Training' in r.stdout
+        outs.append([l.split('(')[0] for l in r.stdout.splitlines() if l.startswith('[Epoch')])
+        assert len(outs[-1]) == 2
+    if graph:
+        assert outs[0] == outs[1], outs

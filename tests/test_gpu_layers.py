@@ -440,3 +440,33 @@ def test_wgrad_winograd(case):
     e4, e2, e32 = rel_err(dw4.cpu().double(), w64.grad), rel_err(dw.cpu().double(), w64.grad), rel_err(w.grad.double(), w64.grad)
     print(f'wgrad {case}: max err / max |dW| vs fp64: F(4x4) {e4:.2e}, F(2x2) {e2:.2e}, torch fp32 {e32:.2e}')
     assert e4 < 1e-5
+
+
+def test_winograd4_padding_rows_never_reach_a_result():
+    """The engine feeds the F(4x4) plane GEMM uninitialised plane padding (V rows T..Tp of torch.empty workspaces).  That is safe only
+    because the output transform reads t < T and the weight-gradient kernel masks m >= T.  Pinned here by poisoning: the layer wrappers
+    fill those rows with NaN (forward, data gradient), and the head-style weight gradient takes the forward's poisoned V -- every
+    result must stay finite and equal the reference."""
+    from object_detection_torch2_amd import ops
+    N, H, W, cin, cout = 3, 19, 19, 256, 100          # 75 tiles per plane, padded to 128
+    zprev = rnd(N, cin, H, W, seed=61)
+    scale, shift = rnd(cin, seed=62), rnd(cin, seed=63) + 0.3
+    w = rnd(cout, cin, 3, 3, seed=64, scale=0.05).requires_grad_(True)
+    a = F.relu(zprev * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    y = F.conv2d(a, w, None, padding=1)
+    dy = rnd(*y.shape, seed=65)
+    y.backward(dy)
+    z, _, V = ops.conv3x3_winograd4(ops.to_nhwc(zprev.to(DEV)), w.detach().to(DEV), in_scale=scale.to(DEV), in_shift=shift.to(DEV), return_v=True)
+    T = N * 5 * 5
+    Vp = V.view(36, -1, cin)
+    assert Vp.shape[1] == 128 and torch.isnan(Vp[:, T:]).all() and torch.isfinite(Vp[:, :T]).all()
+    assert torch.isfinite(z).all() and rel_err(z.permute(0, 3, 1, 2).cpu(), y.detach()) < 1e-4
+    cpad = (cout + 31) // 32 * 32
+    dyp = ops.to_nhwc(dy.to(DEV), pad_to=cpad)
+    dw, _ = ops.conv2d_wgrad(ops.to_nhwc(zprev.to(DEV)), dyp, tuple(w.shape), pad=1, in_scale=scale.to(DEV), in_shift=shift.to(DEV),
+                             winograd=4, wino_v=V, want_bias=False)
+    assert torch.isfinite(dw).all() and rel_err(dw.cpu(), w.grad) < 5e-5
+    w2 = rnd(cout, 256, 3, 3, seed=66, scale=0.05)
+    dx_ref = torch.nn.grad.conv2d_input((N, 256, H, W), w2, dy, padding=1)
+    dx = ops.conv3x3_dgrad_winograd4(dyp, w2.to(DEV))
+    assert torch.isfinite(dx).all() and rel_err(dx.permute(0, 3, 1, 2).cpu(), dx_ref) < 1e-4

@@ -191,25 +191,6 @@ def test_product_library_refuses_probe_tile_codes():
         p.tile = code
         assert lib.ssdhip_conv2d_nhwc(ctypes.byref(p), None) == _lib.EINVAL
         assert b'tile' in lib.ssdhip_last_error()
-    import os
-    assert not os.path.exists(os.path.join(os.path.dirname(_lib.LIB_PATH), '..', '..', 'scripts', 'probes', 'mfma_shape_probe')) or True
-
-
-def test_product_library_refuses_probe_tile_codes():
-    """Tile codes >= 1,000,000 select A/B and timing-only ablation kernels (some return wrong results by design).  They are compiled
-    into libssdhip_probes.so only; the product library must reject them as invalid arguments (checked before any launch, so fake
-    device pointers are safe here)."""
-    import ctypes
-    lib = _lib.load()
-    p = _lib.ConvParams()
-    p.x, p.w, p.y = 0x1000, 0x2000, 0x3000
-    p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout = 16, 1, 128, 256, 1, 128, 256
-    p.R, p.S, p.stride, p.pad, p.KP, p.mode, p.accumulate, p.compute = 1, 1, 1, 0, 256, 0, 0, 0
-    p.y_batch_stride, p.rows_per_img, p.w_img_stride = 128 * 256, 128, 256 * 256
-    for code in (1128128, 6128128, 7128128, 8128128, 9128128, 41128128):
-        p.tile = code
-        assert lib.ssdhip_conv2d_nhwc(ctypes.byref(p), None) == _lib.EINVAL
-        assert b'tile' in lib.ssdhip_last_error()
 
 
 
@@ -244,3 +225,93 @@ def test_winograd4_matrices_are_exact():
     grows = re.search(r'const double G\[6\]\[3\] = \{(.*?)\};', src, re.S).group(1)
     vals = [Fr(a.replace('.0', '')) / Fr(b.replace('.0', '')) if b else Fr(a.replace('.0', '')) for a, b in re.findall(r'(-?[0-9.]+)(?: / ([0-9.]+))?', grows)]
     assert vals == [v for r in G for v in r]
+
+
+ASAN_CLIENT = r"""
+#include <stdio.h>
+#include <string.h>
+#include <stdint.h>
+#include "%(root)s/include/ssdhip.h"
+/* every call below must be rejected by the host-side argument checks BEFORE any launch (there is no GPU here): null pointers, zero and
+   negative extents, channel counts the kernels do not tile, overflowing sizes.  Run under AddressSanitizer + UBSan. */
+static int bad = 0;
+#define REJECT(expr) do { int rc_ = (int)(expr); if (rc_ >= 0) { printf("NOT REJECTED: %%s -> %%d\n", #expr, rc_); bad++; } \
+                          else if (!ssdhip_last_error() || !ssdhip_last_error()[0]) { printf("NO MESSAGE: %%s\n", #expr); bad++; } } while (0)
+int main(void) {
+    float* F = (float*)0x1000;                 /* fake device pointers: never dereferenced on the host */
+    ssdhip_conv_params p; memset(&p, 0, sizeof p);
+    REJECT(ssdhip_conv2d_nhwc(&p, NULL));
+    REJECT(ssdhip_conv2d_nhwc(NULL, NULL));
+    p.x = F; p.w = F; p.y = F; p.N = 2; p.Hi = 8; p.Wi = 8; p.Cin = 48; p.Ho = 8; p.Wo = 8; p.Cout = 64; p.R = 3; p.S = 3; p.stride = 1; p.pad = 1; p.KP = 448;
+    REJECT(ssdhip_conv2d_nhwc(&p, NULL));                       /* Cin not 4 / multiple of 32 */
+    p.Cin = 64; p.KP = 576; p.N = -1;
+    REJECT(ssdhip_conv2d_nhwc(&p, NULL));
+    p.N = 2; p.tile = 96096;
+    REJECT(ssdhip_conv2d_nhwc(&p, NULL));
+    p.tile = 0; p.stride = 0;
+    REJECT(ssdhip_conv2d_nhwc(&p, NULL));
+    p.stride = 1; p.N = 1 << 30; p.Hi = 1 << 15; p.Wi = 1 << 15; p.Ho = 1 << 15; p.Wo = 1 << 15;      /* M overflows 32 bits */
+    REJECT(ssdhip_conv2d_nhwc(&p, NULL));
+    REJECT(ssdhip_normalize_nchw_to_nhwc4(NULL, F, 1, 8, 8, NULL));
+    REJECT(ssdhip_normalize_nchw_to_nhwc4(F, F, 0, 8, 8, NULL));
+    REJECT(ssdhip_pack_conv_weight(F, F, 64, 64, 3, 3, 100, 64, 576, 0, NULL));
+    REJECT(ssdhip_pack_conv_weight(NULL, F, 64, 64, 3, 3, 128, 64, 576, 0, NULL));
+    int T = 0, Tp = 0;
+    REJECT(ssdhip_winograd_tiles(0, 8, 8, &T, &Tp));
+    REJECT(ssdhip_winograd4_tiles(1, 8, 8, 100, &T, &Tp));
+    REJECT(ssdhip_winograd_input(F, NULL, NULL, F, 1, 8, 8, 30, NULL));
+    REJECT(ssdhip_winograd4_input(F, NULL, NULL, F, 1, 8, 8, 64, 3, NULL));      /* Tp smaller than the tile count */
+    REJECT(ssdhip_winograd4_weight(F, NULL, 64, 64, 128, 64, NULL));
+    REJECT(ssdhip_winograd4_output(F, NULL, NULL, NULL, 0, 1, 8, 8, 64, 128, NULL));
+    int32_t maps[3] = {38, 38, 4};
+    REJECT(ssdhip_default_boxes(NULL, maps, 1, 0.2, 0.9, NULL));
+    REJECT(ssdhip_default_boxes(F, maps, 0, 0.2, 0.9, NULL));
+    REJECT(ssdhip_multibox_loss_fwd(F, F, F, 0, 8732, 8, 21, 1.0f, 0.25f, F, (int32_t*)F, F, F, NULL));
+    REJECT(ssdhip_multibox_loss_fwd(F, F, NULL, 2, 8732, 8, 21, 1.0f, 0.25f, F, (int32_t*)F, F, F, NULL));
+    REJECT(ssdhip_decode_score(NULL, F, 1, 8732, 21, NULL));
+    REJECT(ssdhip_nms(F, 1, 200000, 21, 0.5f, NULL, NULL));
+    REJECT(ssdhip_nms_ws(F, 1, 8732, 21, 0.5f, NULL, NULL, NULL));
+    REJECT(ssdhip_adam_multi_tensor(NULL, NULL, NULL, 1, 8192, NULL, NULL));
+    REJECT(ssdhip_bn_finalize(F, 0, 64, 100, F, F, NULL, NULL, 0.1f, 1e-5f, F, F, F, F, NULL, NULL));
+    REJECT(ssdhip_bn_relu_pool(F, F, F, F, 1, 8, 8, 30, 1, 0, NULL));
+    REJECT(ssdhip_conv_rgb3x3(F, F, F, NULL, NULL, 1, 8, 8, 64, NULL));
+    REJECT(ssdhip_wino_fused_conv(F, F, F, NULL, NULL, F, NULL, NULL, 1, 8, 8, 24, 64, 0, NULL));
+    REJECT(ssdhip_conv_bf16(F, F, F, F, 0, NULL, 1, 8, 8, 24, 64, 0, NULL));
+    ssdhip_wgrad_params g; memset(&g, 0, sizeof g);
+    REJECT(ssdhip_conv2d_wgrad(&g, NULL));
+    REJECT(ssdhip_conv2d_wgrad_winograd4(&g, NULL));
+    /* sizing queries on valid shapes: pure host arithmetic */
+    memset(&p, 0, sizeof p);
+    p.x = F; p.w = F; p.y = F; p.N = 32; p.Hi = 3; p.Wi = 3; p.Cin = 256; p.Ho = 1; p.Wo = 1; p.Cout = 256; p.R = 3; p.S = 3; p.stride = 1; p.pad = 0; p.KP = 2304;
+    p.y_batch_stride = 256;
+    long long ws = (long long)ssdhip_conv2d_ws_bytes(&p);
+    int bm = ssdhip_conv2d_block_m(&p), tile = ssdhip_conv2d_tile(&p);
+    printf("version %%d ws %%lld bm %%d tile %%d stat_rows %%d geo %%lld bad %%d\n", ssdhip_version(), ws, bm, tile,
+           ssdhip_winograd4_stat_rows(32, 38, 38, 512), (long long)ssdhip_wino_fused_geo_bytes(32, 150, 150), bad);
+    return bad ? 1 : 0;
+}
+"""
+
+
+def test_asan_build_of_the_host_side_rejects_bad_arguments(tmp_path):
+    """SURVEY.md section 5 (sanitizers): `make asan` = the library's host side under AddressSanitizer + UndefinedBehaviorSanitizer (device
+    code uninstrumented: GPU ASan needs xnack+, which the pool refuses).  A C client drives the argument-validation paths of the
+    launchers -- null pointers, zero / negative / overflowing extents, untiled channel counts -- and two sizing queries; any
+    out-of-bounds access, signed overflow or misaligned access on those paths aborts the client."""
+    import glob
+    import subprocess
+    csrc = os.path.join(ROOT, 'object_detection_torch2_amd', 'csrc')
+    subprocess.run(['make', '-C', csrc, 'asan', '-j8'], check=True, capture_output=True)
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    rt = glob.glob('/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so')
+    assert rt, 'clang AddressSanitizer runtime not found'
+    src = tmp_path / 'asan_client.c'
+    src.write_text(ASAN_CLIENT % dict(root=ROOT))
+    exe = tmp_path / 'asan_client'
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Werror', '-g', str(src), '-o', str(exe), f'-L{libdir}', '-lssdhip_asan',
+                    f'-Wl,-rpath,{libdir}', f'-Wl,-rpath,{os.path.dirname(rt[0])}'], check=True)
+    env = dict(os.environ, LD_PRELOAD=rt[0], ASAN_OPTIONS='detect_leaks=0:abort_on_error=0:halt_on_error=1',
+               UBSAN_OPTIONS='halt_on_error=1:print_stacktrace=1')
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'bad 0' in r.stdout and 'ERROR: AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stdout + r.stderr
