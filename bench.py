@@ -166,8 +166,9 @@ def main():
                     help='extension (SURVEY 8(f)-4): un-freeze VGG16-bn (187.9 GFLOP/img instead of 72.2); never the headline')
     ap.add_argument('--mode', choices=['train', 'infer'], default='train',
                     help='train (headline, BASELINE configs[2]) or infer (configs[1]: forward + decode + score + NMS)')
-    ap.add_argument('--no-graph', action='store_true',
-                    help='enqueue every step from Python (the eager engine) instead of replaying the captured step (graph_step.py)')
+    ap.add_argument('--graph', action='store_true',
+                    help='replay the captured step (graph_step.py: host enqueue 3.6 -> 0.6 ms per step) instead of enqueueing every launch from '
+                         'Python; opt-in because the eager engine overlaps better on the device (9.7 vs 10.4 ms per fp32 step, DESIGN.md 7a)')
     ap.add_argument('--allreduce', choices=['allreduce', 'rs_ag'], default=os.environ.get('SSD_ALLREDUCE', 'allreduce'),
                     help='N > 1: gradient exchange as all-reduce buckets or as reduce-scatter + all-gather (SURVEY 8(e))')
     ap.add_argument('--grad-dtype', choices=['fp32', 'bf16'], default=os.environ.get('SSD_GRAD_DTYPE', 'fp32'),
@@ -234,7 +235,7 @@ def main():
         running.add_(loss.detach())
 
     runner, step_mode = None, 'eager: every launch enqueued from Python'
-    use_graph = (args.mode == 'train' and not args.no_graph and not args.finetune_backbone and os.environ.get('SSD_NO_GRAPH') != '1'
+    use_graph = (args.mode == 'train' and (args.graph or os.environ.get('SSD_GRAPH') == '1') and not args.finetune_backbone
                  and os.environ.get('SSD_SINGLE_STREAM') != '1')
 
     def step():

@@ -1,16 +1,27 @@
 """The train step of the reference loop (train.py:115-122: zero_grad -> forward -> loss -> backward -> optimizer.step) as replayed
-HIP graphs: host time per step drops from ~3.4 ms of Python + ctypes (≈270 launches) to a few graph launches.
+HIP graphs: host time per step drops from ~3.6 ms of Python + ctypes (≈270 launches) to 0.6 ms (two graph launches).
 
 Shape of a step (MI355X-first, not a capture of the eager call sequence):
 
     backbone stream :  BB(i+1)  ─ frozen VGG16-bn of the NEXT batch: one graph, a linear chain of ≈45 launches
     caller's stream :  T(i)     ─ detector heads + trainable tail forward, MultiBox loss, tail backward, fused Adam of THIS batch:
-                                  one graph (three captured streams inside: layer chain, heads / weight gradients, repacking)
+                                  one graph, by default a linear chain too (`linear_tail`)
 
 The two chains never wait for each other inside a step: what T reads of BB (z + BatchNorm scale / shift of conv_4_3 for det_4_3,
 the last frozen activation for conv_6_1) exists twice, and consecutive batches alternate between the copies (`parity`), so BB(i+1)
 writes copy (i+1)%2 while T(i) reads copy i%2.  Two events per step order them: T(i) waits for BB(i); BB(i+2) waits for T(i).
-That is the schedule the eager engine reaches with its reader events (engine.py), with the host out of the way.
+
+Measured on one MI355X (scripts/graph_probe.py, graph_stream_probe.py): host enqueue 3.6-4.0 -> 0.6 ms per step;
+device time 10.4 ms (fp32) / 5.3 ms (bf16) per step against 9.7 / 4.8 ms for the eager engine, so this mode is opt-in (`--graph`):
+it buys host time, not throughput.  Two findings shape it.  (1) A tail captured WITH its internal concurrency (heads / weight
+gradients / repacking on a forked stream) replays on streams the runtime creates at instantiation with normal priority; which
+hardware queue they land on relative to the backbone stream decides between 10.4 and 14.1 ms (fp32; 5.8 .. 9.7 bf16) for the SAME
+graph launched on different caller streams -- a lottery.  A linear tail replays entirely on the caller's stream: the same time on
+every stream tried.  (2) Why the device time is higher than eager's although the two chains overlap MORE here (rocprofv3 kernel trace of both
+modes, one step: 4.9 ms with two or more kernels running against 2.0 ms): kernels that share the chip stretch each other -- the tail's
+208 launches are busy for 7.4 ms here against 5.9 ms eager (4.3 ms alone), the backbone's for 8.6 against 7.6 (7.35 alone).  The
+densely packed tail meets the backbone's heaviest layers (conv_1_2 .. conv_3_1, persistent grids on 224 CUs); moving the det_4_3
+head behind the backbone in the EAGER engine changes nothing (9.65 vs 9.62 ms), so it is the packing, not a placement.
 
 Data parallelism: the gradient all-reduce stays an eager RCCL call between graph segments -- the engine's hook points cut T into
 T1 (everything up to the last weight gradient) | all-reduce of flat[cut:] | T2 (conv_6_1's weight gradient) | all-reduce of
@@ -18,10 +29,15 @@ flat[:cut] + wait | T3 (Adam).  BB(i+1) is already queued on its own stream and 
 
 Results are bit-identical to the eager step: same kernels, same per-stream order, same buffers (tests/test_gpu_graph_step.py).
 """
+import os
+
 import torch
 
 from . import _lib
 from .model import topology as T
+
+
+_DBG = set(filter(None, os.environ.get('SSD_GS_DEBUG', '').split(',')))      # timing experiments only (scripts/graph_probe.py)
 
 
 class _Cut:
@@ -70,8 +86,9 @@ class GraphedTrainStep:
     do not call optimizer.zero_grad()).  The model must be in train mode with its VGG part frozen (the reference's configuration).
     Capturing does not change parameters, buffers or optimizer state (the warm-up steps it needs are rolled back)."""
 
-    def __init__(self, net, optimizer, default_bboxes, images_shape, targets_shape, alpha=1.0, warmup=2):
+    def __init__(self, net, optimizer, default_bboxes, images_shape, targets_shape, alpha=1.0, warmup=2, linear_tail=None):
         eng = net._engine()
+        self.linear_tail = (os.environ.get('SSD_GS_LINEAR', '1') == '1') if linear_tail is None else bool(linear_tail)
         if not net.training:
             raise RuntimeError('GraphedTrainStep: the module must be in train mode (the reference never calls eval())')
         if not (0 < eng.tail_start < len(eng.stages)) or eng.headless:
@@ -152,6 +169,7 @@ class GraphedTrainStep:
         cap.wait_stream(torch.cuda.current_stream(dev))
         eng._phased = True
         hook, eng.dist_hook = eng.dist_hook, None
+        single = eng.single_stream
         try:
             with torch.cuda.stream(cap):
                 # eager passes through exactly the code that is captured next: lazy buffers of both parities, packed weight images,
@@ -171,6 +189,7 @@ class GraphedTrainStep:
                     self._backbone(parity)
                     rec.end()
                     self._bb_graphs.append(rec.items[0])
+                eng.single_stream = single or self.linear_tail     # linear tail: heads / weight gradients / repacking in line on one stream
                 for parity in (0, 1):
                     # every trainable layer's packed image is stale by construction at this point of a step (Adam just ran): make the
                     # capture see it that way, so the repacking launches are part of the graph
@@ -186,6 +205,7 @@ class GraphedTrainStep:
         finally:
             eng.dist_hook = hook
             eng._phased = False
+            eng.single_stream = single
         torch.cuda.current_stream(dev).wait_stream(cap)
         self.net._hip_epoch += 1             # whatever an eager forward finds packed is not what the restored weights say
 
@@ -200,11 +220,12 @@ class GraphedTrainStep:
         p = self._next_parity
         bb = self._bb_stream
         bb.wait_event(ready_event if ready_event is not None else torch.cuda.current_stream(self.dev).record_event())
-        if self._t_done[p] is not None:
+        if self._t_done[p] is not None and 'nowait_t' not in _DBG:
             bb.wait_event(self._t_done[p])           # the tail that read this parity's hand-over buffers
         images.record_stream(bb)
         with torch.cuda.stream(bb):
-            self._x.copy_(images)
+            if 'nocopy' not in _DBG:
+                self._x.copy_(images)
             self._bb_graphs[p].replay()
             self._bb_done[p].record(bb)
         self._fed.append(p)
@@ -222,8 +243,14 @@ class GraphedTrainStep:
         _lib.require_gpu(targets)
         p = self._fed.pop(0)
         main = torch.cuda.current_stream(self.dev)
-        main.wait_event(self._bb_done[p])
-        if g == self.G:
+        if 'trace' in _DBG and not getattr(self, '_traced', False):
+            self._traced = True
+            print(f'[graph_step] step on stream {main} priority {main.priority}; backbone stream priority {self._bb_stream.priority}', flush=True)
+        if 'nowait_bb' not in _DBG:
+            main.wait_event(self._bb_done[p])
+        if 'nocopy' in _DBG:
+            pass
+        elif g == self.G:
             self._targets.copy_(targets)
         else:
             self._targets.zero_()                    # zero rows are padding: they never match a prior (ssd.py:231-250)

@@ -15,7 +15,7 @@ import pathlib
 import torch
 import torch.nn as nn
 
-from .. import _lib
+from .. import _lib, torch_ops
 from . import topology as T
 from .engine import Engine
 
@@ -54,19 +54,11 @@ class _SSDForward(torch.autograd.Function):
 
 
 class _MultiBoxLoss(torch.autograd.Function):
+    """SSD.loss (ssd.py:181-229) on torch.ops.ssdhip.multibox_loss_fwd / _bwd (csrc/torch_ops.cpp -> ssdhip_multibox_loss_*)."""
+
     @staticmethod
     def forward(ctx, outputs, targets, dboxes, alpha, threshold):
-        lib = _lib.load()
-        N, P, row = outputs.shape
-        G = targets.shape[1]
-        dev = outputs.device
-        terms = torch.empty(3, N, P, device=dev, dtype=torch.float32)
-        cnt = torch.empty(N, device=dev, dtype=torch.int32)
-        sel = torch.empty(N, 8, device=dev, dtype=torch.float32)
-        loss = torch.empty(1, device=dev, dtype=torch.float32)
-        _lib.check(lib.ssdhip_multibox_loss_fwd(_lib.ptr(outputs), _lib.ptr(targets), _lib.ptr(dboxes), N, P, G, row - 4,
-                                                float(alpha), float(threshold), _lib.ptr(terms), _lib.ptr(cnt), _lib.ptr(sel),
-                                                _lib.ptr(loss), _lib.stream()), 'SSD.loss')
+        loss, terms, sel = torch_ops.load().multibox_loss_fwd(outputs, targets, dboxes, float(alpha), float(threshold))
         ctx.save_for_backward(outputs, targets, dboxes, terms, sel)
         ctx.alpha, ctx.threshold = float(alpha), float(threshold)
         return loss[0]
@@ -74,13 +66,8 @@ class _MultiBoxLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_loss):
         outputs, targets, dboxes, terms, sel = ctx.saved_tensors
-        N, P, row = outputs.shape
-        G = targets.shape[1]
-        grad = torch.empty_like(outputs)
         g = _lib.f32c(grad_loss).reshape(1)
-        _lib.check(_lib.load().ssdhip_multibox_loss_bwd(_lib.ptr(outputs), _lib.ptr(targets), _lib.ptr(dboxes), N, P, G, row - 4,
-                                                        ctx.alpha, ctx.threshold, _lib.ptr(terms), _lib.ptr(sel), _lib.ptr(g),
-                                                        _lib.ptr(grad), _lib.stream()), 'SSD.loss backward')
+        grad = torch_ops.load().multibox_loss_bwd(outputs, targets, dboxes, ctx.alpha, ctx.threshold, terms, sel, g)
         return grad, None, None, None, None
 
 
@@ -171,21 +158,13 @@ class SSD(nn.Module):
 
     @staticmethod
     def default_bboxes_on(device, topo=T.SSD300) -> torch.Tensor:
-        import ctypes
-        maps = (ctypes.c_int32 * (3 * len(topo.box_maps)))(*[v for m in topo.box_maps for v in m])
-        out = torch.empty(topo.num_priors(), 4, device=device, dtype=torch.float32)
-        with torch.cuda.device(device):
-            _lib.check(_lib.load().ssdhip_default_boxes(_lib.ptr(out), maps, len(topo.box_maps), topo.s_min, topo.s_max, _lib.stream()),
-                       'default_boxes')
-        return out
+        maps = [int(v) for m in topo.box_maps for v in m]
+        return torch_ops.load().default_boxes(maps, float(topo.s_min), float(topo.s_max), torch.device(device))
 
     def normalize(self, x: torch.Tensor) -> torch.Tensor:
         """vgg16.py:103-115 as a stand-alone op (the forward fuses it with the NHWC conversion)."""
         _lib.require_gpu(x)
-        x = _lib.f32c(x)
-        N, _, H, W = x.shape
-        y = torch.empty(N, H, W, 4, device=x.device, dtype=torch.float32)
-        _lib.check(_lib.load().ssdhip_normalize_nchw_to_nhwc4(_lib.ptr(x), _lib.ptr(y), N, H, W, _lib.stream()), 'normalize')
+        y = torch_ops.load().normalize_nchw_to_nhwc4(_lib.f32c(x))
         return y[..., :3].permute(0, 3, 1, 2)
 
     # ---- reference API -------------------------------------------------------------------------------------

@@ -6,7 +6,7 @@ from pathlib import Path
 import torch
 from torch.nn.utils.rnn import pad_sequence
 
-from . import _lib
+from . import _lib, torch_ops
 
 
 def collate_fn(batch):
@@ -41,7 +41,7 @@ def decode_score_(outputs: torch.Tensor, df: torch.Tensor) -> torch.Tensor:
     df = _lib.f32c(df)
     if tuple(df.shape) != (P, 4):
         raise ValueError(f'default boxes must be ({P}, 4), got {tuple(df.shape)}')
-    _lib.check(_lib.load().ssdhip_decode_score(_lib.ptr(outputs), _lib.ptr(df), N, P, row - 4, _lib.stream()), 'decode_score')
+    torch_ops.load().decode_score_(outputs, df)
     return outputs
 
 
@@ -68,11 +68,7 @@ def calc_iou(t: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
         raise ValueError(f'calc_iou: bad shapes {tuple(t.shape)} {tuple(s.shape)}')
     N, T, rt = t.shape
     S, rs = s.shape[1], s.shape[2]
-    out = torch.empty(N, T, S, device=t.device, dtype=torch.float32)
-    if T == 0 or S == 0:
-        return out
-    _lib.check(_lib.load().ssdhip_calc_iou(_lib.ptr(t), _lib.ptr(s), N, T, S, rt, rs, _lib.ptr(out), _lib.stream()), 'calc_iou')
-    return out
+    return torch_ops.load().calc_iou(t, s)
 
 
 _nms_ws = {}
@@ -90,21 +86,19 @@ def non_maximum_suppression(outputs: torch.Tensor, iou_thresh: float = 0.5, retu
         raise ValueError(f'expected (N, P, 4 + C) with C >= 2, got {tuple(outputs.shape)}')
     work = outputs if (outputs.is_contiguous() and outputs.dtype == torch.float32) else _lib.f32c(outputs).clone()
     N, P, row = work.shape
-    keep = torch.empty(N, P, dtype=torch.uint8, device=work.device)
-    lib = _lib.load()
+    ops = torch_ops.load()
     if variant in ('ws', 'auto'):
         key = (N, P, str(work.device))
         ws = _nms_ws.get(key)
         if ws is None:
-            ws = torch.empty(lib.ssdhip_nms_ws_bytes(N, P), dtype=torch.uint8, device=work.device)
+            ws = torch.empty(ops.nms_ws_bytes(N, P), dtype=torch.uint8, device=work.device)
             _nms_ws.clear()
             _nms_ws[key] = ws
-        fn = lib.ssdhip_nms_ws_per_class if per_class else lib.ssdhip_nms_ws
-        _lib.check(fn(_lib.ptr(work), N, P, row - 4, float(iou_thresh), _lib.ptr(keep), _lib.ptr(ws), _lib.stream()), 'nms')
+        keep = ops.nms_(work, float(iou_thresh), ws, bool(per_class))
     else:
         if per_class:
             raise ValueError("per_class NMS runs on the workspace variant (variant='ws' or 'auto')")
-        _lib.check(lib.ssdhip_nms(_lib.ptr(work), N, P, row - 4, float(iou_thresh), _lib.ptr(keep), _lib.stream()), 'nms')
+        keep = ops.nms_(work, float(iou_thresh), None, False)
     if work is not outputs:
         outputs.copy_(work)
     return (outputs, keep) if return_keep else outputs

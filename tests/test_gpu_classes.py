@@ -74,9 +74,9 @@ def test_forward_and_train_step_with_five_classes():
     # of the backbone into output differences an order above those of the large maps; measured 1.93e-3 with every backbone layer on
     # the F(2x2) kernels (SSD_WINOGRAD=f2), 2.04e-3 with conv_3_2 .. conv_5_3 on F(4x4) (at batch 32: 3.7e-4 / 3.9e-4 over all priors,
     # profiles/r03_d_full_batch_parity.txt)
-    assert err[:, 8692:].max() < 4e-3
+    assert err[:, 8692:].max() < 4e-3             # the same network at batch 32 holds 1e-3 on every prior: tests/test_gpu_configs.py
     loss = net.loss(out, torch.from_numpy(tg).to(DEV), torch.from_numpy(df).to(DEV))
-    assert abs(loss.item() - float(O.loss(o, tg, df))) < 2e-3
+    assert abs(loss.item() - float(O.loss(o, tg, df))) < 1e-4      # north-star bound (measured 3.8e-6: tests/tools/bounds_probe.py)
     loss.backward()
     got = dict(net.named_train_params())
     for k in names:

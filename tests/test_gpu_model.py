@@ -72,7 +72,7 @@ def test_gradients_vs_oracle_autograd(env):
     out_o.backward(torch.from_numpy(O.loss_grad(o, tg, df)))
     out = net(torch.from_numpy(ims).to(DEV))
     loss = net.loss(out, torch.from_numpy(tg).to(DEV), torch.from_numpy(df).to(DEV))
-    assert abs(loss.item() - float(O.loss(o, tg, df))) < 2e-3
+    assert abs(loss.item() - float(O.loss(o, tg, df))) < 1e-4      # north-star bound (measured 0: tests/tools/bounds_probe.py)
     loss.backward()
     got = dict(net.named_train_params())
     for k in names:

@@ -315,3 +315,23 @@ def test_asan_build_of_the_host_side_rejects_bad_arguments(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'bad 0' in r.stdout and 'ERROR: AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stdout + r.stderr
+
+
+def test_torch_library_ops_are_registered():
+    """TORCH_LIBRARY(ssdhip) (csrc/torch_ops.cpp): the wrapper library loads without a GPU, registers the minimum operator
+    set of 8(b) with tensor-typed schemas, reports the C library's version and refuses CPU tensors (no fallback)."""
+    import torch
+    from object_detection_torch2_amd import torch_ops
+    S = torch_ops.load()
+    assert S.version() == _lib.load().ssdhip_version()
+    want = ['default_boxes', 'normalize_nchw_to_nhwc4', 'pack_conv_weight', 'conv2d_nhwc', 'conv2d_wgrad', 'bn_finalize', 'bn_relu_pool',
+            'multibox_loss_fwd', 'multibox_loss_bwd', 'decode_score_', 'nms_', 'nms_ws_bytes', 'calc_iou', 'adam_multi_tensor_']
+    for name in want:
+        schema = str(getattr(S, name).default._schema)
+        assert schema.startswith(f'ssdhip::{name}('), schema
+    assert 'Tensor(a!) outputs' in str(S.nms_.default._schema)                      # in-place like utils.py:114
+    assert S.nms_ws_bytes(32, 8732) == _lib.load().ssdhip_nms_ws_bytes(32, 8732)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        S.decode_score_(torch.zeros(1, 10, 25), torch.zeros(10, 4))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        S.multibox_loss_fwd(torch.zeros(1, 10, 25), torch.zeros(1, 2, 25), torch.zeros(10, 4), 1.0, 0.25)
