@@ -6,8 +6,8 @@
 //
 // Reference call sites replaced (paths relative to the reference's src/): see include/ssdhip.h per entry point.
 #include <ATen/ATen.h>
-#include <ATen/hip/HIPContext.h>
-#include <c10/hip/HIPGuard.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/library.h>
 
 #include <vector>
@@ -34,10 +34,11 @@ void need(const at::Tensor& t, const char* name, at::ScalarType dt = at::kFloat)
 }
 void need_opt(const c10::optional<at::Tensor>& t, const char* name) { if (t.has_value() && t->defined()) need(*t, name); }
 
-struct Ctx {       // device guard + the stream torch is enqueueing on for that device
-    c10::hip::HIPGuard guard;
+struct Ctx {       // device guard + the stream torch is enqueueing on for that device (ROCm builds of torch name the device type "cuda")
+    c10::hip::HIPGuardMasqueradingAsCUDA guard;
     void* stream;
-    explicit Ctx(const at::Tensor& t) : guard(t.device()), stream((void*)at::hip::getCurrentHIPStream(t.device().index()).stream()) {}
+    explicit Ctx(const at::Tensor& t)
+        : guard(t.device()), stream((void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream()) {}
 };
 
 // ---- A9 SSD._get_default_bboxes (model/ssd.py:108-133): maps = flat [m, n, anchors] per feature map, host ints

@@ -448,7 +448,7 @@ def test_winograd4_padding_rows_never_reach_a_result():
     fill those rows with NaN (forward, data gradient), and the head-style weight gradient takes the forward's poisoned V -- every
     result must stay finite and equal the reference."""
     from object_detection_torch2_amd import ops
-    N, H, W, cin, cout = 3, 19, 19, 256, 100          # 75 tiles per plane, padded to 128
+    N, H, W, cin, cout = 3, 19, 19, 256, 128          # 75 tiles per plane, padded to 128
     zprev = rnd(N, cin, H, W, seed=61)
     scale, shift = rnd(cin, seed=62), rnd(cin, seed=63) + 0.3
     w = rnd(cout, cin, 3, 3, seed=64, scale=0.05).requires_grad_(True)

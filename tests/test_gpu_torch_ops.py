@@ -95,7 +95,9 @@ def test_loss_decode_nms_ops_match_the_oracle(S):
     t2 = torch.from_numpy(want.copy()).to(DEV)
     keep2 = S.nms_(t2, 0.5, None, False)                                              # all-LDS variant: same keep set
     assert torch.equal(keep, keep2) and torch.equal(tt, t2)
-    iou = S.calc_iou(tt[:, :64], tt[:, 64:200])
+    iou = S.calc_iou(tt[:, :64].contiguous(), tt[:, 64:200].contiguous())
+    with pytest.raises(ValueError, match='contiguous'):
+        S.calc_iou(tt[:, :64], tt[:, 64:200])
     assert np.array_equal(iou.cpu().numpy(), O.calc_iou(tt[:, :64].cpu().numpy(), tt[:, 64:200].cpu().numpy()))     # bit-exact (G6)
     with pytest.raises(ValueError):
         S.multibox_loss_fwd(o, t[:, :, :20].contiguous(), d, 1.0, 0.25)
