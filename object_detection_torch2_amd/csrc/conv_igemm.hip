@@ -24,6 +24,9 @@
 #include "common.h"
 
 // gemm_planes.hip: LDS-DMA staged plane GEMM (Winograd domain)
+long long ssdhip_gemm_planes_queue_ws_bytes(void);
+int ssdhip_gemm_planes_queue(const float* v, const float* u, float* y, int M, int K, int Cout, int rows_per_plane, long long u_plane_stride,
+                             void* ws, hipStream_t st);
 int ssdhip_gemm_planes_dma(const float* v, const float* u, float* y, int M, int K, int Cout, int rows_per_plane, long long u_plane_stride,
                            int BM, int BN, int tpb, hipStream_t st, int abl);
 
@@ -519,6 +522,29 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
+// tiles-per-block rule of the one-slot-per-block plane GEMM (see ssdhip_conv2d_nhwc)
+static int plane_tpb(int64_t tiles, int Cin) {
+    int tpb = (int)(tiles / ((int64_t)ssdhip_cu_count() * 6));
+    if (tpb < 1 || tpb == 2) tpb = 1;
+    if (tpb > 8) tpb = 8;
+    if (Cin >= 256 && tpb > 3) tpb = 3;
+    return tpb;
+}
+
+// Work-queue kernel or one slot per block?  In tile-times on 2 x CUs resident slots: blocks of tpb tiles run in whole rounds (3,600 one-tile
+// blocks on 512 slots: 8; 6,552 tiles in three-tile blocks: 15), the queue pays the exact share (7.03; 12.8) plus ~5 % per item and a
+// start-up term.  Measured (scripts/plane_queue_probe.py): conv_3_2 557 -> 481 us, conv_4_1 318 -> 296, conv_4_2 508 -> 497; where the rounds
+// already fit (conv_6_1: 3.94 of 4; det_4_3) the slot form stays 7 % ahead.
+static bool plane_queue_wins(int64_t MB, int NB, int Cin) {
+    const int64_t tiles = MB * NB, slots = 2 * (int64_t)ssdhip_cu_count();
+    if (tiles < 4 * slots) return false;        // short launches: the queue's start-up and split-piece hand-off cost more than a partial round (1,188 tiles: 107 vs 92 us)
+    const int tpb = plane_tpb(tiles, Cin);
+    const int64_t blocks = ((MB + tpb - 1) / tpb) * NB;
+    const double slot_cost = (double)((blocks + slots - 1) / slots) * tpb;
+    const double queue_cost = (double)tiles / (double)slots * 1.05 + 0.25;
+    return queue_cost < 0.98 * slot_cost;
+}
+
 int choose_tile(const ssdhip_conv_params* p, int& BM, int& BN) {
     if (p->tile % 1000000) { BM = (p->tile / 1000) % 1000; BN = p->tile % 1000; }
     else {
@@ -618,10 +644,7 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
         // (measured on conv_4_1 / conv_4_2 (K = 256 / 512, 3,600 tiles) and conv_3_2 (K = 256, 6,552 tiles) of SSD300 at batch 32 only;
         // other shapes inherit the rule unmeasured)
         const int64_t tiles = (int64_t)a.MB * a.NB;
-        a.tpb = (int)(tiles / ((int64_t)ssdhip_cu_count() * 6));
-        if (a.tpb < 1 || a.tpb == 2) a.tpb = 1;
-        if (a.tpb > 8) a.tpb = 8;
-        if (p->Cin >= 256 && a.tpb > 3) a.tpb = 3;      // K >= 256 (conv_3_2 / conv_3_3 F(4x4) planes, 6,552 tiles): 3 tiles 532-537 us, 4 tiles 544-553 (three runs)
+        a.tpb = plane_tpb(tiles, p->Cin);                // K >= 256 (conv_3_2 / conv_3_3 F(4x4) planes, 6,552 tiles): 3 tiles 532-537 us, 4 tiles 544-553 (three runs)
         // plain row-major planes: stage with the LDS-DMA engine (gemm_planes.hip) unless tile code 9xxxxxx asks for the
         // register-staged kernel (A/B comparison in scripts/wino_bench.py)
         int probe = 0;
@@ -630,6 +653,15 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
         if (code >= 40 && code < 50) a.tpb = code - 40 + 1;
         probe = code == 7 ? 1 : code == 6 ? 2 : code == 8 ? 4 : code == 3 ? 3 : code == 9 ? 9 : 0;
 #endif
+        // 128 x 128 tiles at K >= 256 with a caller workspace: the persistent work-queue kernel (no tile quantisation, one pipeline fill per
+        // launch; gemm_planes.hip).  Without a workspace (and for every other tile): the one-launch-slot-per-block kernel below.
+        if (probe == 0 && p->tile == 128128 && BM == 128 && BN == 128 && p->KP == p->Cin && p->Cin % BK == 0 && p->Cin >= 256 && p->ws &&
+            p->ws_bytes >= ssdhip_gemm_planes_queue_ws_bytes() && plane_queue_wins(a.MB, a.NB, p->Cin)) {
+            int rc = ssdhip_gemm_planes_queue(p->x, p->w, p->y, a.M, p->Cin, p->Cout, p->rows_per_img, p->w_img_stride, p->ws, (hipStream_t)stream);
+            if (rc != SSDHIP_OK) { ssdhip_set_error("conv2d: plane GEMM work-queue kernel not available on this device"); return rc; }
+            SSDHIP_CHECK_LAUNCH();
+            return SSDHIP_OK;
+        }
         if (probe != 9 && !(BM == 64 && BN == 64) && p->KP == p->Cin && p->Cin % BK == 0 && (p->Cin >= 256 || (p->Cin == 128 && BM == 128 && BN == 128))) {   // other K = 128 tiles: register staging measured faster
             int rc = ssdhip_gemm_planes_dma(p->x, p->w, p->y, a.M, p->Cin, p->Cout, p->rows_per_img, p->w_img_stride, BM, BN, a.tpb,
                                             (hipStream_t)stream, probe);
@@ -693,7 +725,14 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
 int64_t ssdhip_conv2d_ws_bytes(const ssdhip_conv_params* p) {
     // bytes of split-K workspace this launch can use (0: the launch does not split).  Sized for the largest split plan_split picks.
     int BM, BN;
-    if (!p || choose_tile(p, BM, BN) != SSDHIP_OK || p->Cin == 4 || p->rows_per_img != 0 || p->KP <= 0) return 0;
+    if (!p || choose_tile(p, BM, BN) != SSDHIP_OK || p->Cin == 4 || p->KP <= 0) return 0;
+    if (p->rows_per_img != 0) {
+        // plane GEMMs (Winograd domain): 128 x 128 tiles at K >= 256 run on the work-queue kernel when given this workspace (its first 4 KiB
+        // zero before the first launch; the kernel leaves them zero)
+        const bool q = p->tile == 128128 && p->KP == p->Cin && p->Cin % BK == 0 && p->Cin >= 256 && p->R == 1 && !p->bias && !p->stats && !p->accumulate &&
+                       !p->in_scale && ((int64_t)p->N * p->Ho * p->Wo) % 128 == 0 && p->y_batch_stride == (int64_t)p->Ho * p->Wo * p->Cout;
+        return q && plane_queue_wins(((int64_t)p->N * p->Ho * p->Wo) / 128, cdiv(p->Cout, 128), p->Cin) ? (int64_t)ssdhip_gemm_planes_queue_ws_bytes() : 0;
+    }
     const int64_t M = (int64_t)p->N * p->Ho * p->Wo;
     if (p->mode == 1 && p->stride == 2 && p->R == 3 && M >= 8192) return 0;       // parity-class launches: large grids
     int kt_per;

@@ -183,9 +183,299 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, Plan
     }
 }
 
+
+// ---- Work-queue form of the 128 x 128 / 8-wave kernel (round 4): the dominant launches of the step (conv_3_2 .. conv_4_3 planes: 3,600 and
+// 6,552 tiles of 8 or 16 K-steps) lose 10-15 % to tile quantisation in the form above -- 3,600 one-tile blocks over 512 resident slots
+// are 7.03 rounds paid as 8, 6,552 tiles in three-tile blocks are 12.8 tile-times paid as 15 (scripts/plane_k_probe.py: the asymptote
+// of the K loop is 131 TF, a 16-step tile reaches 121-125) -- and re-pay launch, first-DMA latency and store drain per block.  Here:
+//   grid      2 blocks per CU, persistent; block -> XCD = blockIdx & 7 (the hardware's round-robin placement)
+//   queues    one atomic work queue per XCD over that XCD's contiguous eighth of the tiles (n-tiles of an m-chunk adjacent, as above:
+//             the blocks of an XCD work on neighbouring tiles at any time, so a V tile is fetched once into their L2); dynamic, so
+//             a CU that shares its time with another stream's kernels simply takes fewer tiles
+//   pipeline  a block knows its next item before it starts the current one (items are grabbed two ahead), so the first K-step of the
+//             next tile streams in under the last K-step of the current one: one pipeline fill per launch instead of one per block
+//   last round  when the tiles of an XCD leave R < S / 2 tiles for the last round of its S blocks, those R tiles are queued as
+//             R * SP pieces of KT / SP K-steps; a piece stores its 128 x 128 partial sums to the workspace, and the block that
+//             arrives LAST at the tile's counter adds the SP partials in slice order (fixed order: bit-reproducible whatever the
+//             arrival order) and writes M.  The last round then costs KT / SP K-steps + one 64-KiB-per-slice reduction.
+// Control words (first 4 KiB of the workspace, zero before the first launch, left zero by every launch): queue heads [0..7], exited
+// blocks [8], piece counters [64 + 64 xcd + tile].
+constexpr int PQ_CTL_BYTES = 4096;      // control words
+struct PlaneQArgs {
+    const float* v;
+    const float* u;
+    float* y;
+    int* ctl;
+    float* part;
+    long long u_plane_stride;
+    int M, K, KT, Cout, rows_per_plane, MB, NB, S;
+};
+
+// Queue grab of the work-queue kernel as a raw instruction WITHOUT a wait: the compiler puts s_waitcnt vmcnt(0) behind a
+// memory operation whose result it sees (at the join of `if (thread 0)` that is every K-step, right behind the DMA issue: no latency cover
+// left, half the speed).  The K loop ends every step with an explicit s_waitcnt vmcnt(0); results are only used behind one.
+__device__ __forceinline__ int pq_grab_nowait(int* q) {
+    int r, one = 1;
+    asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(r) : "v"(q), "v"(one) : "memory");
+    return r;
+}
+// Sum of the SP slice partials of one 128 x 128 tile in slice order (bit-reproducible whatever the arrival order), written to M.  Kept out
+// of line: it runs once per remainder tile, and inlined it costs the K loop 30 registers.
+__device__ __noinline__ void plane_piece_reduce(const float* part, int SP, float* y, int m0, int n0, int Cout, int tid) {
+    // (thread 0 ran the agent acquire -- this CU's L1 is invalidated -- and every wave passed a barrier behind its vmcnt(0))
+    const float4* src = reinterpret_cast<const float4*>(part);
+    for (int k = 0; k < (128 * 128 / 4) / 512; ++k) {
+        const int e4 = tid + 512 * k, row = e4 >> 5, c4 = e4 & 31;
+        float4 s = src[e4];
+        for (int sl = 1; sl < SP; ++sl) {
+            const float4 t = src[(size_t)sl * (128 * 128 / 4) + e4];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        const int co = n0 + 4 * c4;
+        float* o = y + ((size_t)(m0 + row) * Cout + co);
+        if (co + 3 < Cout) *reinterpret_cast<float4*>(o) = s;
+        else { if (co < Cout) o[0] = s.x; if (co + 1 < Cout) o[1] = s.y; if (co + 2 < Cout) o[2] = s.z; }
+    }
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_planes_queue_kernel(PlaneQArgs a) {
+    constexpr int BM = 128, BN = 128, WNC = 4, RPP = 64, WROWS = 64, WCOLS = 32, MT = 2, AL = 2, BL = 2;
+    __shared__ __attribute__((aligned(1024))) float lds[2 * (BM + BN) * LROW];
+    float* As = lds;
+    float* Bs = lds + 2 * BM * LROW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WNC, wn = wave % WNC;
+    const int KT = a.KT, S = a.S;
+    const int xcd = blockIdx.x & 7;
+    // this XCD's tiles [base, base + Tx); F full rounds of S tiles, then R tiles as R * SP pieces
+    const int T = a.MB * a.NB, tq = T >> 3, tr = T & 7;
+    const int base = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, Tx = tq + (xcd < tr ? 1 : 0);
+    const int F = Tx / S, R = Tx - F * S;
+    int SP = 1;
+    if (R > 0 && 2 * R <= S) { SP = S / R; if (SP > KT) SP = KT; if (SP > 16) SP = 16; }
+    const int n_full = SP > 1 ? F * S : Tx, n_items = n_full + (SP > 1 ? R * SP : 0);      // SP == 1: the last round's tiles are ordinary items
+    int* qhead = a.ctl + xcd;
+    // Block-wide broadcasts of thread 0's queue grabs go through two words of LDS behind a workgroup barrier.  (A mailbox in global memory,
+    // read by every wave for itself, was tried to keep the block at exactly 64 KiB of LDS: one wave reading a stale word while another
+    // read the fresh one sends the two into different items -- mismatched barrier counts, a hung kernel.  64 KiB + 16 B still fits twice
+    // into the CU's 160 KiB.)
+    __shared__ int pub[4];                 // [0]: next item id; [2]: "this block reduces the tile"
+
+    // an item is wave-uniform: every field is forced into scalar registers (the integer divisions below run on the vector unit)
+    struct Item { int m0, n0, k0, k1, piece, pt, plane; };
+    auto decode = [&](int id) {
+        Item it;
+        int tile = base + id, k0 = 0, k1 = KT, piece = -1, pt = 0;
+        if (id >= n_full) {
+            const int j = id - n_full, sl = j % SP;
+            pt = j / SP;
+            tile = base + n_full + pt;
+            k0 = sl * KT / SP; k1 = (sl + 1) * KT / SP;
+            piece = xcd * S + j;
+        }
+        const int mchunk = tile / a.NB;
+        it.m0 = __builtin_amdgcn_readfirstlane(mchunk * BM);
+        it.n0 = __builtin_amdgcn_readfirstlane((tile - mchunk * a.NB) * BN);
+        it.k0 = __builtin_amdgcn_readfirstlane(k0); it.k1 = __builtin_amdgcn_readfirstlane(k1);
+        it.piece = __builtin_amdgcn_readfirstlane(piece); it.pt = __builtin_amdgcn_readfirstlane(pt);
+        it.plane = __builtin_amdgcn_readfirstlane(mchunk * BM / a.rows_per_plane);
+        return it;
+    };
+
+    // the first item of a block is its slot index (no round trip before the first DMA); the queue hands out ids from S on
+    int cur_id = (int)(blockIdx.x >> 3);
+
+    const int lrow = tid >> 3, pchunk = tid & 7;
+    const unsigned src_chunk = (unsigned)((pchunk ^ ((lrow >> 1) & 7)) * 16);
+    const char* vb = reinterpret_cast<const char*>(a.v);
+    const unsigned rowK = (unsigned)a.K * 4u;
+    float* a_dst = As + (8 * wave) * LROW;
+    float* b_dst = Bs + (8 * wave) * LROW;
+    auto issue = [&](const Item& it, int kt, int buf) {
+        const unsigned kb = (unsigned)kt * (BK * 4);
+        const unsigned a_off = (unsigned)(it.m0 + lrow) * rowK + src_chunk + kb, b_off = (unsigned)(it.n0 + lrow) * rowK + src_chunk + kb;
+        const char* ub = reinterpret_cast<const char*>(a.u) + (size_t)it.plane * (size_t)a.u_plane_stride * 4;
+#pragma unroll
+        for (int i = 0; i < AL; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(vb + (a_off + (unsigned)(RPP * i) * rowK)), (lptr_t)(a_dst + (buf * BM + RPP * i) * LROW), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < BL; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(ub + (b_off + (unsigned)(RPP * i) * rowK)), (lptr_t)(b_dst + (buf * BN + RPP * i) * LROW), 16, 0, 0);
+    };
+
+    const int frow = lane & 31, fh = lane >> 5, fx = (frow >> 1) & 7;
+    unsigned fko[4];
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) fko[kc] = (unsigned)(((2 * kc + fh) ^ fx) * 16);
+    const unsigned a_lds = (unsigned)(uintptr_t)(lptr_t)(As + (wm * WROWS + frow) * LROW);
+    const unsigned b_lds = (unsigned)(uintptr_t)(lptr_t)(Bs + (wn * WCOLS + frow) * LROW);
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    int buf = 0;
+#ifdef PQ_TRACE      // timing experiments only: per block (start, then per item: id, end time) in the partial-sum area behind the slices
+    long long* trace = reinterpret_cast<long long*>(a.part + (size_t)8 * S * BM * BN) + (size_t)blockIdx.x * 64;
+    int tn = 0;
+    if (tid == 0) { trace[0] = wall_clock64(); trace[1] = cur_id; tn = 2; }
+#endif
+    if ((unsigned)cur_id < (unsigned)n_items) {
+        Item cur = decode(cur_id);
+        issue(cur, cur.k0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                   // the first K-step has landed for every wave
+        while (true) {
+            // The id of the NEXT item (one ahead: the blocks of an XCD then work on 64 consecutive tiles at any time, like consecutively
+            // dispatched blocks would -- grabbing two ahead spread them over twice the span and cost conv_6_1 its L2 hits): atomic grab at
+            // the item's first K-step (thread 0, no wait), mailbox store behind that step's vmcnt(0), acknowledged by the next step's;
+            // every thread loads it at the top of the last-but-one K-step and decodes it behind that step's wait, in time for the last
+            // K-step to stream the next tile's first operands in.  Items of fewer than 4 K-steps (split pieces) fetch it at their end.
+            const bool fast = cur.k1 - cur.k0 >= 4;
+            int nxt_id = n_items, nn = 0;
+            bool known = false, prefetched = false;
+            Item nx = cur;
+            for (int kt = cur.k0; kt < cur.k1; ++kt) {
+                const unsigned ab = a_lds + (unsigned)(buf * BM * LROW * 4), bb = b_lds + (unsigned)(buf * BN * LROW * 4);
+                f32x4 fa[2][MT], fb[2];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[0][i]) : "v"(ab + fko[0]), "n"(i * 32 * LROW * 4));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(fb[0]) : "v"(bb + fko[0]));
+                if (kt + 1 < cur.k1) issue(cur, kt + 1, buf ^ 1);
+                else if (known && (unsigned)nxt_id < (unsigned)n_items) { issue(nx, nx.k0, buf ^ 1); prefetched = true; }
+                const bool grab = kt == cur.k0 && tid == 0;
+                const bool fetch = fast && kt + 2 == cur.k1;
+                int grabbed = 0;
+                if (grab) grabbed = pq_grab_nowait(qhead);      // (not to be touched before the s_waitcnt at the end of the step)
+                if (fetch) nn = pub[0];                          // published before this step's opening barrier (the previous step's closing one)
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) {
+                    const int c = kc & 1;
+                    if (kc < 3) {
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+                            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[c ^ 1][i]) : "v"(ab + fko[kc < 3 ? kc + 1 : 0]), "n"(i * 32 * LROW * 4));
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(fb[c ^ 1]) : "v"(bb + fko[kc < 3 ? kc + 1 : 0]));
+                        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa[c][0]), "+v"(fa[c][1]), "+v"(fb[c]));
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[c][0]), "+v"(fa[c][1]), "+v"(fb[c]));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int el = 0; el < 4; ++el)
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i][el], fb[c][el], acc[i], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (kt + 1 == cur.k1) {            // item finished: M rows (whole tile) or the partial sums of this K slice
+                    const int col = wn * WCOLS + (lane & 31), co = cur.n0 + col;
+                    const int ld = cur.piece < 0 ? a.Cout : BN;
+                    const bool ok = cur.piece >= 0 || co < a.Cout;
+                    // (the asm keeps the 32 row addresses from being hoisted out of the K loop, where they cost 64 registers and spill)
+                    int row0 = wm * WROWS + 4 * (lane >> 5);
+                    asm volatile("" : "+v"(row0));
+                    float* dst = (cur.piece < 0 ? a.y + ((size_t)cur.m0 * a.Cout + co) : a.part + ((size_t)cur.piece * (BM * BN) + col)) + (size_t)row0 * ld;
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            if (ok) dst[(size_t)(i * 32 + (e & 3) + 8 * (e >> 2)) * ld] = acc[i][e];
+                            acc[i][e] = 0.f;
+                        }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(grabbed), "+v"(nn) : : "memory");
+                if (grab) pub[0] = S + grabbed;
+                if (fetch) {
+                    nxt_id = __builtin_amdgcn_readfirstlane(nn);
+                    known = true;
+                    if ((unsigned)nxt_id < (unsigned)n_items) nx = decode(nxt_id);
+                }
+                __builtin_amdgcn_s_barrier();
+                buf ^= 1;
+            }
+            if (cur.piece >= 0) {
+                // Hand-off of the slice's partial sums to whichever block reduces the tile -- possibly on another XCD, whose L2 does not see
+                // this XCD's dirty lines (the block -> XCD mapping above is a locality guess, not a contract).  The form MI355X_MICROARCH.md
+                // lists as valid for plain stores: every storing wave has waited vmcnt(0) (end of the K-step) -> workgroup barrier -> ONE
+                // lane: agent release (L2 write-back) -> vmcnt(0) -> agent-scope atomic add on the tile's counter; the block whose add
+                // returns SP - 1 came last: agent acquire -> vmcnt(0) -> barrier -> plain loads in slice order.
+                __syncthreads();
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    int* cnt = a.ctl + 64 + 64 * xcd + cur.pt;
+                    const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int last = old == SP - 1;
+                    if (last) {
+                        __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // left zero for the next launch
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    }
+                    pub[2] = last;
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (pub[2]) plane_piece_reduce(a.part + (size_t)(xcd * S + cur.pt * SP) * (BM * BN), SP, a.y, cur.m0, cur.n0, a.Cout, tid);
+                __syncthreads();                                 // pub[2] may be rewritten by the next piece
+            }
+            if (!known) {                                        // short item: its grab is only now guaranteed to have reached the mailbox
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                nxt_id = __builtin_amdgcn_readfirstlane(pub[0]);
+                __syncthreads();                                 // everyone has read it before thread 0 publishes the next grab
+                if (nxt_id < n_items) nx = decode(nxt_id);
+            }
+#ifdef PQ_TRACE
+            if (tid == 0 && tn < 62) { trace[tn++] = wall_clock64(); trace[tn++] = nxt_id; }
+#endif
+            if (nxt_id >= n_items) break;
+            cur = nx;
+            if (!prefetched) {
+                issue(cur, cur.k0, buf);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+    }
+    // the last block out of the whole grid leaves the queues at zero for the next launch (every block has stopped grabbing by then)
+    __syncthreads();
+#ifdef PQ_TRACE
+    if (tid == 0) { trace[tn] = wall_clock64(); trace[63] = tn; }
+#endif
+    if (tid == 0) {
+        const int done = __hip_atomic_fetch_add(a.ctl + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == (int)gridDim.x - 1) {
+            for (int i = 0; i < 9; ++i) __hip_atomic_store(a.ctl + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 }  // namespace
 
 // called from ssdhip_conv2d_nhwc (conv_igemm.hip) for plane GEMMs
+// Workspace of the work-queue form: control words + one 128 x 128 partial tile per block slot.
+long long ssdhip_gemm_planes_queue_ws_bytes(void) {
+    const int S = ssdhip_cu_count() * 2 / 8;
+    return PQ_CTL_BYTES + (long long)8 * S * 128 * 128 * 4 + 8 * S * 64 * 8;      // (+ the trace area of PQ_TRACE builds)
+}
+
+// 128 x 128 tiles, K >= 256: the persistent work-queue kernel.  ws: ssdhip_gemm_planes_queue_ws_bytes() bytes whose first 4 KiB were zero
+// before the first launch on it (launches on one workspace must be stream-ordered).
+int ssdhip_gemm_planes_queue(const float* v, const float* u, float* y, int M, int K, int Cout, int rows_per_plane, long long u_plane_stride,
+                             void* ws, hipStream_t st) {
+    PlaneQArgs a;
+    a.v = v; a.u = u; a.y = y; a.u_plane_stride = u_plane_stride;
+    a.ctl = reinterpret_cast<int*>(ws);
+    a.part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + PQ_CTL_BYTES);
+    a.M = M; a.K = K; a.KT = K / BK; a.Cout = Cout; a.rows_per_plane = rows_per_plane;
+    a.MB = M / 128; a.NB = cdiv(Cout, 128);
+    a.S = ssdhip_cu_count() * 2 / 8;
+    if (a.S < 1 || a.S > 64) return SSDHIP_ENOSUP;      // piece counters: 64 per XCD
+    hipLaunchKernelGGL(gemm_planes_queue_kernel, dim3(8 * a.S), dim3(512), 0, st, a);
+    return SSDHIP_OK;
+}
+
 int ssdhip_gemm_planes_dma(const float* v, const float* u, float* y, int M, int K, int Cout, int rows_per_plane, long long u_plane_stride,
                            int BM, int BN, int tpb, hipStream_t st, int abl) {
     PlaneArgs a;

@@ -115,6 +115,7 @@ class Engine:
         self._no_splitk = os.environ.get('SSD_NO_SPLITK') == '1'
         self._no_fused = os.environ.get('SSD_NO_FUSED_WINOGRAD') == '1'
         self._no_patch = os.environ.get('SSD_NO_BF16_PATCH') == '1'
+        self._no_plane_queue = os.environ.get('SSD_NO_PLANE_QUEUE') == '1'      # A/B: every plane GEMM on the one-slot-per-block kernel
         self._z_bf16 = os.environ.get('SSD_BF16_Z', 'bf16') == 'bf16'
         # frozen 3x3 backbone layers on maps up to SSD_W4_MAX_MAP = 160 px (SSD300: conv_3_2 .. conv_5_3 at 75 .. 19 px; SSD512: from conv_3_2 at 128 px): Winograd F(4x4,3x3) (csrc/winograd4.hip: 1.78x fewer MFMA flops
         # than F(2x2), 2.7x its rounding error, still 8x inside the per-layer bound of the tests); SSD_WINOGRAD=f2 keeps F(2x2) everywhere
@@ -314,7 +315,7 @@ class Engine:
             spec.wino_key = key
         return spec.wino_u
 
-    def _plane_gemm(self, p, tp, cin, cout, w_plane_stride, what, planes=16):
+    def _plane_gemm(self, p, tp, cin, cout, w_plane_stride, what, planes=16, spec=None):
         """ssdhip_conv2d_nhwc as 16 (F(2x2)) or 36 (F(4x4)) plane GEMMs; the kernel addresses its input with 32-bit byte offsets (2^30
         elements), so big batches run the planes in groups (same kernel, pointers advanced)."""
         groups = 1
@@ -323,12 +324,26 @@ class Engine:
         per = planes // groups
         x0, w0, y0 = p.x, p.w, p.y
         p.N = per
+        # 128 x 128 plane GEMMs whose tile count fits the resident slots badly (conv_3_2 .. conv_4_3) run on the work-queue kernel when handed
+        # its workspace (gemm_planes.hip); its control words start at zero and every launch leaves them at zero
+        need = self.lib.ssdhip_conv2d_ws_bytes(ctypes.byref(p))
+        if need > 0 and spec is not None and not self._no_plane_queue:
+            bufs = spec.__dict__.setdefault('planeq_ws', {})
+            key = (what.split(' ')[0], torch.cuda.current_device())
+            ws = bufs.get(key)
+            if ws is None or ws.numel() * 4 < need:
+                ws = torch.zeros((need + 3) // 4, device=torch.device('cuda', torch.cuda.current_device()), dtype=torch.float32)
+                bufs[key] = ws
+            p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
         for gi in range(groups):
             p.x = x0 + gi * per * tp * cin * 4
             p.w = w0 + gi * per * w_plane_stride * 4
             p.y = y0 + gi * per * tp * cout * 4
             _lib.check(self.lib.ssdhip_conv2d_nhwc(ctypes.byref(p), _lib.stream()), what)
+        queued = bool(p.ws)
         p.x, p.w, p.y, p.N = x0, w0, y0, planes
+        p.ws, p.ws_bytes = None, 0
+        return queued
 
     def _wino4_ok(self, c, g, sizing=False):
         """Layers on the Winograd F(4x4,3x3) passes: forward of the frozen backbone's 3x3/s1/p1 layers and of the first trainable layer
@@ -380,14 +395,14 @@ class Engine:
         p.tile = tile
         p.rows_per_img, p.w_img_stride = tp, spec.rows_pad * spec.cin
         if self.prof is None:
-            self._plane_gemm(p, tp, spec.cin, spec.cout, spec.rows_pad * spec.cin, f'winograd4 gemm {spec.name}', planes=36)
+            self._plane_gemm(p, tp, spec.cin, spec.cout, spec.rows_pad * spec.cin, f'winograd4-gemm {spec.name}', planes=36, spec=spec)
         else:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            self._plane_gemm(p, tp, spec.cin, spec.cout, spec.rows_pad * spec.cin, f'winograd4 gemm {spec.name}', planes=36)
+            queued = self._plane_gemm(p, tp, spec.cin, spec.cout, spec.rows_pad * spec.cin, f'winograd4-gemm {spec.name}', planes=36, spec=spec)
             e1.record()
             self.prof.append(dict(layer=spec.name + ' (F(4x4) winograd-domain GEMM)',
-                                  kernel='gemm_planes_dma_kernel<%d, 128, 0, 8, 0>' % (tile // 1000),
+                                  kernel='gemm_planes_queue_kernel' if queued else 'gemm_planes_dma_kernel<%d, 128, 0, 8, 0>' % (tile // 1000),
                                   direct_flops=2.0 * N * h * w * spec.cin * spec.cout * 9,
                                   flops=2.0 * 36 * tp * spec.cin * spec.cout, flops_unpadded=2.0 * 36 * T * spec.cin * spec.cout, e0=e0, e1=e1))
         return _lib.check(L.ssdhip_winograd4_output(_lib.ptr(Mo), _lib.ptr(bias), _lib.ptr(z), _lib.ptr(stats), 0, N, h, w, spec.cout, tp, st),
@@ -411,11 +426,11 @@ class Engine:
         p.tile = 128128 if (16 * tp // 128) * ((spec.cout + 127) // 128) > 2000 else 64128
         p.rows_per_img, p.w_img_stride = tp, spec.rows_pad * spec.cin
         if self.prof is None:
-            self._plane_gemm(p, tp, spec.cin, spec.cout, spec.rows_pad * spec.cin, f'winograd gemm {spec.name}')
+            self._plane_gemm(p, tp, spec.cin, spec.cout, spec.rows_pad * spec.cin, f'winograd-gemm {spec.name}', spec=spec)
         else:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            self._plane_gemm(p, tp, spec.cin, spec.cout, spec.rows_pad * spec.cin, f'winograd gemm {spec.name}')
+            self._plane_gemm(p, tp, spec.cin, spec.cout, spec.rows_pad * spec.cin, f'winograd-gemm {spec.name}', spec=spec)
             e1.record()
             self.prof.append(dict(layer=spec.name + ' (winograd-domain GEMM)',
                                   # the symbol rocprofv3 shows: K >= 256 planes and the K = 128 specialisation run on the LDS-DMA kernel
@@ -448,14 +463,14 @@ class Engine:
         p.tile = 128128 if cp <= 128 else 128064
         p.rows_per_img, p.w_img_stride = tp, rows * spec.cin
         if self.prof is None:
-            self._plane_gemm(p, tp, spec.cin, cp, rows * spec.cin, f'winograd4 gemm {spec.name}', planes=36)
+            self._plane_gemm(p, tp, spec.cin, cp, rows * spec.cin, f'winograd4-gemm-head {spec.name}', planes=36, spec=spec)
         else:               # roofline leg of bench.py: every launch of the plane GEMM is bracketed, so its average matches rocprofv3's
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            self._plane_gemm(p, tp, spec.cin, cp, rows * spec.cin, f'winograd4 gemm {spec.name}', planes=36)
+            queued = self._plane_gemm(p, tp, spec.cin, cp, rows * spec.cin, f'winograd4-gemm-head {spec.name}', planes=36, spec=spec)
             e1.record()
             self.prof.append(dict(layer=spec.name + ' (F(4x4) winograd-domain GEMM, head)',
-                                  kernel=('gemm_planes_dma_kernel<128, 128, 0, 8, 0>' if p.tile == 128128 else 'gemm_planes_dma_kernel<128, 64, 0, 4, 0>'),
+                                  kernel=('gemm_planes_queue_kernel' if queued else 'gemm_planes_dma_kernel<128, 128, 0, 8, 0>' if p.tile == 128128 else 'gemm_planes_dma_kernel<128, 64, 0, 4, 0>'),
                                   direct_flops=2.0 * N * h * w * spec.cin * spec.cout * 9,
                                   flops=2.0 * 36 * tp * spec.cin * cp,
                                   flops_unpadded=2.0 * 36 * N * ((h + 3) // 4) * ((w + 3) // 4) * spec.cin * spec.cout, e0=e0, e1=e1))
@@ -478,7 +493,7 @@ class Engine:
         p.R, p.S, p.stride, p.pad, p.KP, p.mode, p.accumulate = 1, 1, 1, 0, spec.cin, 0, 0
         p.tile = 128128 if cp <= 128 else 128064
         p.rows_per_img, p.w_img_stride = tp, _rup(cp, 128) * spec.cin
-        self._plane_gemm(p, tp, spec.cin, cp, _rup(cp, 128) * spec.cin, f'winograd gemm {spec.name}')
+        self._plane_gemm(p, tp, spec.cin, cp, _rup(cp, 128) * spec.cin, f'winograd-gemm-head {spec.name}', spec=spec)
         _lib.check(L.ssdhip_winograd_output_head(_lib.ptr(Mo), _lib.ptr(bias), out_ptr, out_batch_stride, N, h, w, spec.cout, cp, st),
                    f'winograd_output_head {spec.name}')
 
@@ -1021,7 +1036,7 @@ class Engine:
         p.R, p.S, p.stride, p.pad, p.KP, p.mode, p.accumulate = 1, 1, 1, 0, spec.co_pad, 0, 0
         p.tile = 128128
         p.rows_per_img, p.w_img_stride = tp, rows * spec.co_pad
-        self._plane_gemm(p, tp, spec.co_pad, spec.cin, rows * spec.co_pad, f'winograd4 gemm (dgrad {spec.name})', planes=36)
+        self._plane_gemm(p, tp, spec.co_pad, spec.cin, rows * spec.co_pad, f'winograd4-gemm-dgrad {spec.name}', planes=36, spec=spec)
         _lib.check(L.ssdhip_winograd4_output(_lib.ptr(Mo), None, _lib.ptr(dx), None, int(accumulate), N, h, w, spec.cin, tp, st),
                    f'winograd4_output (dgrad {spec.name})')
 
@@ -1055,7 +1070,7 @@ class Engine:
         if spec.cin < 128:
             p.tile = 128064
         p.rows_per_img, p.w_img_stride = tp, rows * spec.cout
-        self._plane_gemm(p, tp, spec.cout, spec.cin, rows * spec.cout, f'winograd gemm (dgrad {spec.name})')
+        self._plane_gemm(p, tp, spec.cout, spec.cin, rows * spec.cout, f'winograd-gemm-dgrad {spec.name}', spec=spec)
         _lib.check(L.ssdhip_winograd_output(_lib.ptr(Mo), None, _lib.ptr(dx), None, N, h, w, spec.cin, st), f'winograd_output (dgrad {spec.name})')
 
     def _dgrad(self, spec, dy, dx, N, hdy, wdy, hin, win, accumulate):

@@ -470,3 +470,50 @@ def test_winograd4_padding_rows_never_reach_a_result():
     dx_ref = torch.nn.grad.conv2d_input((N, 256, H, W), w2, dy, padding=1)
     dx = ops.conv3x3_dgrad_winograd4(dyp, w2.to(DEV))
     assert torch.isfinite(dx).all() and rel_err(dx.permute(0, 3, 1, 2).cpu(), dx_ref) < 1e-4
+
+
+def test_plane_gemm_work_queue_matches_slot_kernel():
+    """The persistent work-queue form of the 128 x 128 plane GEMM (gemm_planes.hip: per-XCD queues, last round split along K with a
+    fixed-order reduce) against the one-slot-per-block kernel on the same planes: whole tiles bit-equal (same K order), split tiles
+    equal up to the summation order, nothing left unwritten, control words back at zero, bit-reproducible -- also when the block -> XCD
+    placement is shifted by one-block launches in front (blocks of one queue then no longer sit on the XCD the kernel guessed)."""
+    import ctypes
+    from object_detection_torch2_amd import _lib
+    lib = _lib.load()
+    for tp, cin, cout in ((3200, 256, 512), (4352, 256, 256)):         # conv_4_1 at batch 32 (split last round); 2,448 tiles without a split
+        rows_pad = (cout + 127) // 128 * 128
+        g = torch.Generator(device=DEV).manual_seed(5)
+        U = torch.randn(36 * rows_pad * cin, device=DEV, generator=g) * 0.02
+        V = torch.randn(36 * tp * cin, device=DEV, generator=g)
+        p = _lib.ConvParams()
+        p.x, p.w, p.y_batch_stride = V.data_ptr(), U.data_ptr(), tp * cout
+        p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout = 36, 1, tp, cin, 1, tp, cout
+        p.R, p.S, p.stride, p.pad, p.KP, p.mode, p.accumulate, p.tile = 1, 1, 1, 0, cin, 0, 0, 128128
+        p.rows_per_img, p.w_img_stride = tp, rows_pad * cin
+        st = _lib.stream()
+        need = lib.ssdhip_conv2d_ws_bytes(ctypes.byref(p))
+        assert need > 0, 'the host rule should pick the work-queue kernel for this launch'
+        ws = torch.zeros((need + 3) // 4, device=DEV)
+        M0 = torch.full((36 * tp * cout,), float('nan'), device=DEV)
+        M1 = torch.full((36 * tp * cout,), float('nan'), device=DEV)
+        p.y = M0.data_ptr()
+        _lib.check(lib.ssdhip_conv2d_nhwc(ctypes.byref(p), st), 'slot kernel')
+        p.y, p.ws, p.ws_bytes = M1.data_ptr(), ws.data_ptr(), ws.numel() * 4
+        _lib.check(lib.ssdhip_conv2d_nhwc(ctypes.byref(p), st), 'queue kernel')
+        torch.cuda.synchronize()
+        assert torch.isfinite(M0).all() and torch.isfinite(M1).all()
+        tiles_differ = int((M0.view(-1, 128, cout) != M1.view(-1, 128, cout)).any(dim=1).view(-1, cout // 128, 128).any(dim=2).sum())
+        assert tiles_differ <= 8 * 31, tiles_differ                                 # at most the split tiles of the last round (< 32 per XCD)
+        assert (M0 - M1).abs().max().item() <= 4e-6 * M0.abs().max().item()
+        ref = (V.view(36, tp, cin)[11, -128:].double() @ U.view(36, rows_pad, cin)[11, :cout].double().t()).float()
+        assert ((M1.view(36, tp, cout)[11, -128:] - ref).abs().max() / ref.abs().max()).item() < 5e-6
+        first = M1.clone()
+        tick, hyper = torch.zeros(1, dtype=torch.int32, device=DEV), torch.zeros(8, device=DEV)
+        for shift in (0, 1, 3, 6):
+            M1.fill_(float('nan'))
+            for _ in range(shift):
+                _lib.check(lib.ssdhip_adam_tick(_lib.ptr(tick), _lib.ptr(hyper), st), 'one-block launch')
+            _lib.check(lib.ssdhip_conv2d_nhwc(ctypes.byref(p), st), 'queue kernel')
+            torch.cuda.synchronize()
+            assert torch.equal(M1, first), shift
+            assert bool((ws[:1024].view(torch.int32) == 0).all()), shift
