@@ -85,6 +85,10 @@ typedef struct {
 } ssdhip_conv_params;
 int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream);
 int64_t ssdhip_conv2d_ws_bytes(const ssdhip_conv_params* p);   /* split-K workspace this launch can use (0 = it does not split) */
+/* For a plane GEMM (rows_per_img != 0) with tile = 128128 and K >= 256 whose tile count fits the resident block slots badly, the same query returns
+ * the workspace of the persistent work-queue kernel (csrc/gemm_planes.hip: per-XCD atomic queues, last round split along K, fixed-order reduce:
+ * bit-reproducible): 4 KiB of control words -- ZERO before the first launch on this workspace, left zero by every launch -- plus one 128 x 128
+ * partial tile per block slot.  Launches that share a workspace must be stream-ordered.  Without it the launch runs one block per tile slot. */
 /* m-block size the auto/explicit tile choice will use for `stats` (rows of the partial table = ceil(M/BM)) */
 int ssdhip_conv2d_block_m(const ssdhip_conv_params* p);
 /* BM*1000+BN the call will run with (profiling / bench bookkeeping) */

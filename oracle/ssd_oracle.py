@@ -387,6 +387,79 @@ def forward(sd, x, num_classes=21, training=True, collect=None, imsize=300):
     return torch.cat(ys, dim=1)
 
 
+def forward_bf16(sd, x, num_classes=21, imsize=300):
+    """CPU restatement of the PACKAGE's bf16 compute mode (BASELINE configs[3] / [4]; no reference counterpart: the reference is fp32 only).
+    It rounds where the kernels round, so that a bf16 run can be compared at rounding level instead of against fp32:
+      * conv_1_1 (RGB) stays fp32; every other convolution and every detector head multiplies bf16 operands with fp32 accumulation:
+        the input is relu(bn(z_prev)) (+ 2x2 max-pool) computed in fp32 and rounded ONCE to bf16, the weights are rounded to bf16;
+      * BatchNorm (train mode) takes its statistics from the fp32 accumulators; where a frozen layer's pre-BN map is only read by the
+        next layer's apply pass (conv_1_2 .. conv_5_2 except conv_4_3, which feeds a head) that map is stored as bf16 and the apply pass
+        reads the rounded values;
+      * backward: the gradient dy arriving at a convolution or head output is rounded to bf16 for its weight and data gradient (the
+        staging of wgrad_bf16_kernel / the BF16 template); BatchNorm / ReLU backward, bias gradients, loss and parameters are fp32.
+    Train mode only (the reference never calls eval()); running statistics are updated like nn.BatchNorm2d."""
+    import torch
+    import torch.nn.functional as F
+
+    def r16(t):                                    # round to nearest even, straight-through for autograd
+        return t + (t.detach().bfloat16().float() - t.detach())
+
+    class GradRound(torch.autograd.Function):      # identity; the gradient passing back through is rounded to bf16
+        @staticmethod
+        def forward(ctx, t):
+            return t.view_as(t)
+
+        @staticmethod
+        def backward(ctx, g):
+            return g.bfloat16().float()
+
+    mean = torch.tensor(MEAN, dtype=torch.float32).reshape(1, 3, 1, 1)
+    std = torch.tensor(STD, dtype=torch.float32).reshape(1, 3, 1, 1)
+    x = x.sub(mean).div(std)
+    layers = feature_layers(imsize)
+    dets = {d['src']: d for d in detector_layers(num_classes, imsize)}
+    convs = [l for l in layers if l['kind'] == 'conv']
+    last_frozen = [l['name'] for l in convs if l['frozen']][-1]
+    ys, z, z_used, first = [], None, None, True
+    for li, l in enumerate(layers):
+        p = 'features.' + l['name']
+        if l['kind'] == 'conv':
+            w, b = sd[p + '.weight'], sd[p + '.bias']
+            if first:                              # conv_1_1: fp32 kernel on the normalised image
+                z = F.conv2d(x, w, b, stride=l['stride'], padding=l['pad'])
+                first = False
+            else:
+                z = GradRound.apply(F.conv2d(x, r16(w), None, stride=l['stride'], padding=l['pad'])) + b.view(1, -1, 1, 1)
+            tag = l['name'].replace('conv_', '')
+            stored_bf16 = l['frozen'] and l['name'] not in ('conv_1_1', last_frozen) and ('act_' + tag) not in dets
+            z_used = r16(z) if stored_bf16 else z
+        elif l['kind'] == 'bn':
+            g, be = sd[p + '.weight'], sd[p + '.bias']
+            mu = z.mean(dim=(0, 2, 3))
+            var = z.var(dim=(0, 2, 3), unbiased=False)
+            with torch.no_grad():
+                n = z.numel() / z.shape[1]
+                sd[p + '.num_batches_tracked'] += 1
+                sd[p + '.running_mean'].mul_(0.9).add_(0.1 * mu)
+                sd[p + '.running_var'].mul_(0.9).add_(0.1 * var * n / (n - 1))
+            scale = g / torch.sqrt(var + 1e-5)
+            shift = be - mu * scale
+            x = z_used * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        elif l['kind'] == 'act':
+            x = F.relu(x)
+            if l['name'] in dets:
+                d = dets[l['name']]
+                q = 'detectors.' + d['name']
+                y = GradRound.apply(F.conv2d(r16(x), r16(sd[q + '.weight']), None, padding=1)) + sd[q + '.bias'].view(1, -1, 1, 1)
+                ys.append(y.permute(0, 2, 3, 1).reshape(x.shape[0], -1, num_classes + 4))
+            nxt = layers[li + 1] if li + 1 < len(layers) else None
+            if nxt is None or nxt['kind'] != 'pool':
+                x = r16(x)                         # the next convolution's operand: one rounding behind BN.ReLU
+        else:
+            x = r16(F.max_pool2d(x, 2, 2, padding=l['pad']))          # ... or behind BN.ReLU + pool (max commutes with the rounding)
+    return torch.cat(ys, dim=1)
+
+
 def adam_step(p, g, m, v, step, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, wd=5e-4):
     """torch.optim.Adam single-tensor semantics (train.py:97): L2 decay added to grad, bias-corrected."""
     g = g + wd * p

@@ -116,3 +116,37 @@ def test_vgg16_oracle_matches_reference_golden(golden):
     assert np.allclose(sd['features.1.running_mean'].numpy(), fx['bn0_running_mean'], rtol=1e-5, atol=1e-8)
     m = O.dropout_mask(9, 0, 1000)
     assert set(np.unique(m).tolist()) == {0.0, 2.0} and 0.4 < (m > 0).mean() < 0.6
+
+
+def test_oracle_bf16_restatement_rounds_where_the_design_says():
+    """oracle.forward_bf16 (checker of the package's bf16 mode; the reference has no bf16 path): with weights and input chosen so that every
+    operand is exactly representable in bf16 the restatement must equal the fp32 forward bit for bit on the first layers, its gradient
+    passes through the roundings (straight-through), and the dy handed to a weight gradient is bf16-rounded."""
+    import torch
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    # the two primitives it is built from
+    t = torch.randn(1000) * 3
+    r = t.bfloat16().float()
+    x = t.clone().requires_grad_(True)
+    y = x + (x.detach().bfloat16().float() - x.detach())
+    assert torch.equal(y.detach(), r)
+    y.sum().backward()
+    assert torch.equal(x.grad, torch.ones_like(x))                  # straight-through
+    # end to end at a tiny batch: close to the fp32 forward at bf16 level, finite gradients for every trainable tensor
+    from object_detection_torch2_amd import synth
+    ims = torch.from_numpy(synth.images(7, 2))
+    sd32, sd16 = O.init_state(1), O.init_state(1)
+    names = O.trainable_param_names()
+    for k in names:
+        sd16[k].requires_grad_(True)
+    with torch.no_grad():
+        a = O.forward(sd32, ims, training=True)
+    b = O.forward_bf16(sd16, ims)
+    rel = ((a - b.detach()).norm() / a.norm()).item()
+    assert 0.01 < rel < 0.2, rel                                    # bf16 operands: percent-level, not fp32-level, not garbage
+    for k in ('features.bn_4_3.running_mean', 'features.bn_11_2.running_var'):
+        assert torch.allclose(sd16[k], sd32[k], rtol=0.2, atol=0.05) and int(sd16[k.rsplit('.', 1)[0] + '.num_batches_tracked']) == 1
+    b.square().mean().backward()
+    assert all(sd16[k].grad is not None and torch.isfinite(sd16[k].grad).all() for k in names)
+    assert sd16['features.conv_6_1.bias'].grad.abs().max() < 1e-6   # a conv bias in front of a train-mode BatchNorm: analytically zero
