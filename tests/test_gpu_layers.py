@@ -480,7 +480,7 @@ def test_plane_gemm_work_queue_matches_slot_kernel():
     import ctypes
     from object_detection_torch2_amd import _lib
     lib = _lib.load()
-    for tp, cin, cout in ((3200, 256, 512), (4352, 256, 256)):         # conv_4_1 at batch 32 (split last round); 2,448 tiles without a split
+    for tp, cin, cout in ((3200, 256, 512), (11648, 256, 256)):        # conv_4_1 (3,600 tiles, split last round) and conv_3_2 (6,552, no split) at batch 32
         rows_pad = (cout + 127) // 128 * 128
         g = torch.Generator(device=DEV).manual_seed(5)
         U = torch.randn(36 * rows_pad * cin, device=DEV, generator=g) * 0.02

@@ -565,3 +565,29 @@ def test_pool_fusion_is_bit_identical(env, monkeypatch):
     assert torch.equal(a[0], b[0]) and a[1] == b[1] and torch.equal(a[5], b[5])
     assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
     assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+
+
+@pytest.mark.parametrize('switches', [dict(SSD_NO_FUSED_WINOGRAD='1'), dict(SSD_NO_FUSED_WINOGRAD='1', SSD_WINOGRAD='f2'), dict(SSD_NO_PLANE_QUEUE='1'),
+                                      dict(SSD_NO_SPLITK='1', SSD_NO_POOL_FUSE='1')])
+def test_fallback_routes_run_the_same_network(env, golden, monkeypatch, switches):
+    """The kernels the default route no longer launches stay part of the product (A/B switches, other shapes): conv_c64 for conv_1_2 /
+    conv_2_1 and the three-pass Winograd forms for the wide maps (SSD_NO_FUSED_WINOGRAD), the one-slot-per-block plane GEMM
+    (SSD_NO_PLANE_QUEUE), the un-split tiny-map launches and the unfused pool (SSD_NO_SPLITK, SSD_NO_POOL_FUSE).  Each route must be the
+    same network at model level: forward against the reference's golden rows at the bound of the default route, and against the default
+    route's own output at rounding level."""
+    synth = env['synth']
+    fx = golden('g8_forward.npz')
+    x = torch.from_numpy(synth.images(31, 2)).to(DEV)
+    with torch.no_grad():
+        y0 = make_net(env)(x)
+    for k, v in switches.items():
+        monkeypatch.setenv(k, v)
+    net = make_net(env)
+    with torch.no_grad():
+        y1 = net(x)
+    eng = net._engine()
+    assert eng._no_fused == (switches.get('SSD_NO_FUSED_WINOGRAD') == '1') and eng._no_plane_queue == (switches.get('SSD_NO_PLANE_QUEUE') == '1')
+    assert np.abs(y1.cpu().numpy()[:, ::7] - fx['fwd_train_rows']).max() < 2e-3
+    assert (y1 - y0).abs().max().item() < 2e-3
+    if 'SSD_NO_FUSED_WINOGRAD' in switches:
+        assert not torch.equal(y0, y1)                                   # a different set of kernels really ran
