@@ -588,6 +588,7 @@ def test_fallback_routes_run_the_same_network(env, golden, monkeypatch, switches
     eng = net._engine()
     assert eng._no_fused == (switches.get('SSD_NO_FUSED_WINOGRAD') == '1') and eng._no_plane_queue == (switches.get('SSD_NO_PLANE_QUEUE') == '1')
     assert np.abs(y1.cpu().numpy()[:, ::7] - fx['fwd_train_rows']).max() < 2e-3
-    assert (y1 - y0).abs().max().item() < 2e-3
+    d = (y1 - y0).abs()
+    assert d[:, :8692].max().item() < 1e-3 and d.max().item() < 4e-3      # the 3x3 / 1x1 maps of a batch of two amplify (BatchNorm over 18 / 2 samples)
     if 'SSD_NO_FUSED_WINOGRAD' in switches:
         assert not torch.equal(y0, y1)                                   # a different set of kernels really ran
