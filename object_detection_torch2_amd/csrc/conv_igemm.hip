@@ -618,9 +618,11 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
     // libssdhip_probes.so (make probes; used by scripts/*_probe.py, scripts/*_bench.py), never in the product library
     SSDHIP_REQUIRE(p->tile >= 0 && p->tile < 1000000, "conv2d: tile must be 0 (auto) or one of 128128/128064/64128/64064");
 #endif
-    SSDHIP_REQUIRE(p->compute == 0 || p->compute == 1, "conv2d: compute 0 (fp32 MFMA) or 1 (bf16 MFMA, fp32 accumulate)");
+    SSDHIP_REQUIRE(p->compute == 0 || p->compute == 1 || p->compute == 2, "conv2d: compute 0 (fp32 MFMA), 1 (bf16 MFMA, fp32 accumulate) or 2 (split-bf16 plane GEMM)");
     const bool bf16 = p->compute == 1;
     SSDHIP_REQUIRE(!bf16 || (p->Cin != 4 && p->rows_per_img == 0), "conv2d: bf16 compute is for the plain conv layers");
+    SSDHIP_REQUIRE(p->compute != 2 || (p->rows_per_img > 0 && p->tile == 128128 && p->KP == p->Cin && p->Cin % 32 == 0 && !p->bias && !p->stats && !p->accumulate && !p->in_scale),
+                   "conv2d: compute 2 (fp32 operands as three bf16 terms, six products) is for 128 x 128 plane GEMMs");
     int BM, BN;
     SSDHIP_REQUIRE(choose_tile(p, BM, BN) == SSDHIP_OK, "conv2d: tile must be one of 128128/128064/64128/64064");
     SSDHIP_REQUIRE(p->rows_per_img == 0 || (p->rows_per_img % BM == 0 && p->mode == 0 && p->w_img_stride > 0),
@@ -655,6 +657,12 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
 #endif
         // 128 x 128 tiles at K >= 256 with a caller workspace: the persistent work-queue kernel (no tile quantisation, one pipeline fill per
         // launch; gemm_planes.hip).  Without a workspace (and for every other tile): the one-launch-slot-per-block kernel below.
+        if (p->compute == 2) {
+            int rc = ssdhip_gemm_planes_dma(p->x, p->w, p->y, a.M, p->Cin, p->Cout, p->rows_per_img, p->w_img_stride, BM, BN, a.tpb, (hipStream_t)stream, 100);
+            if (rc != SSDHIP_OK) { ssdhip_set_error("conv2d: split-bf16 plane GEMM needs 128 x 128 tiles"); return rc; }
+            SSDHIP_CHECK_LAUNCH();
+            return SSDHIP_OK;
+        }
         if (probe == 0 && p->tile == 128128 && BM == 128 && BN == 128 && p->KP == p->Cin && p->Cin % BK == 0 && p->Cin >= 256 && p->ws &&
             p->ws_bytes >= ssdhip_gemm_planes_queue_ws_bytes() && plane_queue_wins(a.MB, a.NB, p->Cin)) {
             int rc = ssdhip_gemm_planes_queue(p->x, p->w, p->y, a.M, p->Cin, p->Cout, p->rows_per_img, p->w_img_stride, p->ws, (hipStream_t)stream);

@@ -184,6 +184,156 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, Plan
 }
 
 
+// ---- Split-bf16 form (round 4; OPT-IN, compute = 2; never the default: the headline keeps exact fp32 products).  Same planes, same fp32
+// operands in HBM and LDS, same tile walk as gemm_planes_dma_kernel<128, 128, 0, 8>; only the inner product changes: every fp32 operand
+// value is split in registers into three bf16 terms (a = a1 + a2 + a3 exactly: 8 + 8 + 8 significant bits) and the six cross products
+// a1b1, a1b2, a2b1, a1b3, a2b2, a3b1 -- everything down to 2^-24 of the product -- run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation:
+// 12 MFMAs of 32 cycles per 16 k and wave where the fp32 form issues 16 of 64.  Measured against fp64 (scripts/split_bf16_probe.py,
+// profiles/r04_d_*): 3x SMALLER error than the fp32 MFMA (the bf16 instruction sums 16 products before it rounds into the accumulator).
+typedef __bf16 pl_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 pl_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float pl_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned pl_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pl_pack(float lo, float hi) {          // round-to-nearest-even pair, lo in bits 0-15
+    const pl_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, pl_bf16x2));
+}
+// two fp32 values -> the packed pairs of their three bf16 terms
+__device__ __forceinline__ void pl_split(float x, float y, unsigned& t1, unsigned& t2, unsigned& t3) {
+    t1 = pl_pack(x, y);
+    const float rx = x - __uint_as_float(t1 << 16), ry = y - __uint_as_float(t1 & 0xffff0000u);
+    t2 = pl_pack(rx, ry);
+    t3 = pl_pack(rx - __uint_as_float(t2 << 16), ry - __uint_as_float(t2 & 0xffff0000u));
+}
+// eight consecutive k of one row -> three MFMA operands
+__device__ __forceinline__ void pl_split8(const f32x4& lo, const f32x4& hi, pl_bf16x8 (&t)[3]) {
+    unsigned w[3][4];
+    pl_split(lo.x, lo.y, w[0][0], w[1][0], w[2][0]);
+    pl_split(lo.z, lo.w, w[0][1], w[1][1], w[2][1]);
+    pl_split(hi.x, hi.y, w[0][2], w[1][2], w[2][2]);
+    pl_split(hi.z, hi.w, w[0][3], w[1][3], w[2][3]);
+    pl_u32x4 u[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) u[i] = (pl_u32x4){w[i][0], w[i][1], w[i][2], w[i][3]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = __builtin_bit_cast(pl_bf16x8, u[i]);
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_planes_split_kernel(PlaneArgs a) {
+    constexpr int BM = 128, BN = 128, WNC = 4, RPP = 64, WROWS = 64, WCOLS = 32, MT = 2, AL = 2, BL = 2;
+    __shared__ __attribute__((aligned(1024))) float lds[2 * (BM + BN) * LROW];
+    float* As = lds;
+    float* Bs = lds + 2 * BM * LROW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WNC, wn = wave % WNC;
+    const int KT = a.KT;
+    int t;
+    {
+        const int T = ((a.MB + a.tpb - 1) / a.tpb) * a.NB, bid = blockIdx.x;
+        const int xcd = bid & 7, local = bid >> 3, q = T >> 3, r = T & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int mchunk = t / a.NB, nt_idx = t - mchunk * a.NB;
+    const int mt0 = mchunk * a.tpb, ntl = min(a.tpb, a.MB - mt0);
+    const int m0 = mt0 * BM, n0 = nt_idx * BN;
+    const int lrow = tid >> 3, pchunk = tid & 7;
+    const unsigned src_chunk = (unsigned)((pchunk ^ ((lrow >> 1) & 7)) * 16);
+    const char* vb = reinterpret_cast<const char*>(a.v);
+    const unsigned rowK = (unsigned)a.K * 4u;
+    unsigned a_off = (unsigned)(m0 + lrow) * rowK + src_chunk;
+    const unsigned b_off = (unsigned)(n0 + lrow) * rowK + src_chunk;
+    float* a_dst = As + (8 * wave) * LROW;
+    float* b_dst = Bs + (8 * wave) * LROW;
+    int ld_kt = 0, ld_tile = 0;
+    const char* ub = reinterpret_cast<const char*>(a.u) + (size_t)(m0 / a.rows_per_plane) * (size_t)a.u_plane_stride * 4;
+    auto issue = [&](int buf) {
+        const unsigned kb = (unsigned)ld_kt * (BK * 4);
+#pragma unroll
+        for (int i = 0; i < AL; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(vb + (a_off + (unsigned)(RPP * i) * rowK + kb)), (lptr_t)(a_dst + (buf * BM + RPP * i) * LROW), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < BL; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(ub + (b_off + (unsigned)(RPP * i) * rowK + kb)), (lptr_t)(b_dst + (buf * BN + RPP * i) * LROW), 16, 0, 0);
+        if (++ld_kt == KT) {
+            if (ld_tile + 1 < ntl) {
+                ld_kt = 0; ++ld_tile;
+                a_off += (unsigned)BM * rowK;
+                ub = reinterpret_cast<const char*>(a.u) + (size_t)((m0 + ld_tile * BM) / a.rows_per_plane) * (size_t)a.u_plane_stride * 4;
+            } else {
+                ld_kt = KT - 1;
+            }
+        }
+    };
+    f32x16 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    issue(0);
+    __syncthreads();
+    // bf16 MFMA operand: lane (row = lane & 31, kh = lane >> 5) supplies k = 16 m + 8 kh .. + 7 of its row = the logical 16-B chunks
+    // 4 m + 2 kh and + 1 of the 128-B LDS row; physical chunk = logical ^ ((row >> 1) & 7), so the pair stays inside one aligned 32 B
+    const int frow = lane & 31, kh = lane >> 5, fx = (frow >> 1) & 7;
+    unsigned fko[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) { fko[m][0] = (unsigned)(((4 * m + 2 * kh) ^ fx) * 16); fko[m][1] = (unsigned)(((4 * m + 2 * kh + 1) ^ fx) * 16); }
+    const unsigned a_lds = (unsigned)(uintptr_t)(lptr_t)(As + (wm * WROWS + frow) * LROW);
+    const unsigned b_lds = (unsigned)(uintptr_t)(lptr_t)(Bs + (wn * WCOLS + frow) * LROW);
+    const int total = ntl * KT;
+    int kt_in = 0, m_cur = m0;
+    for (int g = 0; g < total; ++g) {
+        const int buf = g & 1;
+        const unsigned ab = a_lds + (unsigned)(buf * BM * LROW * 4), bb = b_lds + (unsigned)(buf * BN * LROW * 4);
+        f32x4 fa[2][MT][2], fb[2][2];              // [k16 half][m-tile][low / high 16 B]
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[m][i][h]) : "v"(ab + fko[m][h]), "n"(i * 32 * LROW * 4));
+#pragma unroll
+            for (int h = 0; h < 2; ++h) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[m][h]) : "v"(bb + fko[m][h]));
+        }
+        issue(buf ^ 1);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            if (m == 0) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fa[0][1][0]), "+v"(fa[0][1][1]), "+v"(fb[0][0]), "+v"(fb[0][1]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fa[1][1][0]), "+v"(fa[1][1][1]), "+v"(fb[1][0]), "+v"(fb[1][1]));
+            pl_bf16x8 ta[MT][3], tb[3];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) pl_split8(fa[m][i][0], fa[m][i][1], ta[i]);
+            pl_split8(fb[m][0], fb[m][1], tb);
+            // small terms first: (a3 b1) (a2 b2) (a1 b3) (a2 b1) (a1 b2) (a1 b1)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[i][2], tb[0], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[i][1], tb[1], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[i][0], tb[2], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[i][1], tb[0], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[i][0], tb[1], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[i][0], tb[0], acc[i], 0, 0, 0);
+            }
+        }
+        if (++kt_in == KT) {
+            kt_in = 0;
+            const int co = n0 + wn * WCOLS + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m_cur + wm * WROWS + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    if (co < a.Cout) a.y[(size_t)m * a.Cout + co] = acc[i][e];
+                    acc[i][e] = 0.f;
+                }
+            m_cur += BM;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
 // ---- Work-queue form of the 128 x 128 / 8-wave kernel (round 4): the dominant launches of the step (conv_3_2 .. conv_4_3 planes: 3,600 and
 // 6,552 tiles of 8 or 16 K-steps) lose 10-15 % to tile quantisation in the form above -- 3,600 one-tile blocks over 512 resident slots
 // are 7.03 rounds paid as 8, 6,552 tiles in three-tile blocks are 12.8 tile-times paid as 15 (scripts/plane_k_probe.py: the asymptote
@@ -483,6 +633,11 @@ int ssdhip_gemm_planes_dma(const float* v, const float* u, float* y, int M, int 
     a.M = M; a.K = K; a.KT = K / BK; a.Cout = Cout; a.rows_per_plane = rows_per_plane;
     a.MB = M / BM; a.NB = cdiv(Cout, BN); a.tpb = tpb;
     dim3 grid(cdiv(a.MB, a.tpb) * a.NB), block(256);
+    if (abl == 100) {          // compute = 2: the split-bf16 form (opt-in; 128 x 128 tiles only)
+        if (BM != 128 || BN != 128) return SSDHIP_ENOSUP;
+        hipLaunchKernelGGL(gemm_planes_split_kernel, grid, dim3(512), 0, st, a);
+        return SSDHIP_OK;
+    }
 #ifdef SSDHIP_PROBES      // libssdhip_probes.so only: A/B variants and timing-only ablations (abl 1 / 2 return wrong results by design)
     if (abl == 4) { hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128, 0, 4>), grid, block, 0, st, a); return SSDHIP_OK; }      // A/B: the 4-wave block
     if (abl == 1) { hipLaunchKernelGGL((gemm_planes_dma_kernel<128, 128, 1>), grid, block, 0, st, a); return SSDHIP_OK; }

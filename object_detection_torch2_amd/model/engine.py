@@ -116,6 +116,11 @@ class Engine:
         self._no_fused = os.environ.get('SSD_NO_FUSED_WINOGRAD') == '1'
         self._no_patch = os.environ.get('SSD_NO_BF16_PATCH') == '1'
         self._no_plane_queue = os.environ.get('SSD_NO_PLANE_QUEUE') == '1'      # A/B: every plane GEMM on the one-slot-per-block kernel
+        # opt-in, never the default: 128 x 128 plane GEMMs as three bf16 terms per fp32 operand and six products on the bf16 MFMA (csrc/gemm_planes.hip:
+        # error vs fp64 no larger than the fp32 MFMA's, 1.3x its speed); the default keeps exact fp32 products, the reference's arithmetic
+        self._plane_split = os.environ.get('SSD_PLANE_GEMM', 'fp32') == 'bf16x3'
+        if os.environ.get('SSD_PLANE_GEMM', 'fp32') not in ('fp32', 'bf16x3'):
+            raise ValueError("SSD_PLANE_GEMM must be 'fp32' or 'bf16x3'")
         self._z_bf16 = os.environ.get('SSD_BF16_Z', 'bf16') == 'bf16'
         # frozen 3x3 backbone layers on maps up to SSD_W4_MAX_MAP = 160 px (SSD300: conv_3_2 .. conv_5_3 at 75 .. 19 px; SSD512: from conv_3_2 at 128 px): Winograd F(4x4,3x3) (csrc/winograd4.hip: 1.78x fewer MFMA flops
         # than F(2x2), 2.7x its rounding error, still 8x inside the per-layer bound of the tests); SSD_WINOGRAD=f2 keeps F(2x2) everywhere
@@ -326,7 +331,9 @@ class Engine:
         p.N = per
         # 128 x 128 plane GEMMs whose tile count fits the resident slots badly (conv_3_2 .. conv_4_3) run on the work-queue kernel when handed
         # its workspace (gemm_planes.hip); its control words start at zero and every launch leaves them at zero
-        need = self.lib.ssdhip_conv2d_ws_bytes(ctypes.byref(p))
+        if self._plane_split and p.tile == 128128 and cin % 32 == 0:
+            p.compute = 2
+        need = self.lib.ssdhip_conv2d_ws_bytes(ctypes.byref(p)) if p.compute == 0 else 0
         if need > 0 and spec is not None and not self._no_plane_queue:
             bufs = spec.__dict__.setdefault('planeq_ws', {})
             key = (what.split(' ')[0], torch.cuda.current_device())
@@ -342,7 +349,7 @@ class Engine:
             _lib.check(self.lib.ssdhip_conv2d_nhwc(ctypes.byref(p), _lib.stream()), what)
         queued = bool(p.ws)
         p.x, p.w, p.y, p.N = x0, w0, y0, planes
-        p.ws, p.ws_bytes = None, 0
+        p.ws, p.ws_bytes, p.compute = None, 0, 0
         return queued
 
     def _wino4_ok(self, c, g, sizing=False):

@@ -517,3 +517,43 @@ def test_plane_gemm_work_queue_matches_slot_kernel():
             torch.cuda.synchronize()
             assert torch.equal(M1, first), shift
             assert bool((ws[:1024].view(torch.int32) == 0).all()), shift
+
+
+def test_plane_gemm_split_bf16_is_as_exact_as_the_fp32_mfma():
+    """compute = 2 (opt-in): the 128 x 128 plane GEMM with every fp32 operand split into three bf16 terms and six products on the bf16
+    MFMA.  Against an fp64 product its error must not exceed the exact-fp32 MFMA kernel's (measured: rms 8.5e-8 vs 9.9e-8 of max |out|);
+    other tiles and epilogues are refused."""
+    import ctypes
+    from object_detection_torch2_amd import _lib
+    lib = _lib.load()
+    tp, cin, cout = 1408, 512, 384
+    rows_pad = (cout + 127) // 128 * 128
+    g = torch.Generator(device=DEV).manual_seed(9)
+    U = torch.randn(36 * rows_pad * cin, device=DEV, generator=g) * 0.02
+    V = torch.randn(36 * tp * cin, device=DEV, generator=g) * (torch.rand(36 * tp * cin, device=DEV, generator=g) * 4)
+    p = _lib.ConvParams()
+    p.x, p.w, p.y_batch_stride = V.data_ptr(), U.data_ptr(), tp * cout
+    p.N, p.Hi, p.Wi, p.Cin, p.Ho, p.Wo, p.Cout = 36, 1, tp, cin, 1, tp, cout
+    p.R, p.S, p.stride, p.pad, p.KP, p.mode, p.accumulate, p.tile = 1, 1, 1, 0, cin, 0, 0, 128128
+    p.rows_per_img, p.w_img_stride = tp, rows_pad * cin
+    st = _lib.stream()
+    M0 = torch.full((36 * tp * cout,), float('nan'), device=DEV)
+    M2 = torch.full((36 * tp * cout,), float('nan'), device=DEV)
+    p.y, p.compute = M0.data_ptr(), 0
+    _lib.check(lib.ssdhip_conv2d_nhwc(ctypes.byref(p), st), 'fp32')
+    p.y, p.compute = M2.data_ptr(), 2
+    _lib.check(lib.ssdhip_conv2d_nhwc(ctypes.byref(p), st), 'split')
+    torch.cuda.synchronize()
+    assert torch.isfinite(M2).all()
+    e0 = e2 = 0.0
+    for pl in (0, 17, 35):
+        ref = V.view(36, tp, cin)[pl].double() @ U.view(36, rows_pad, cin)[pl, :cout].double().t()
+        sc = ref.abs().max().item()
+        e0 = max(e0, (M0.view(36, tp, cout)[pl].double() - ref).pow(2).mean().sqrt().item() / sc)
+        e2 = max(e2, (M2.view(36, tp, cout)[pl].double() - ref).pow(2).mean().sqrt().item() / sc)
+        assert (M2.view(36, tp, cout)[pl].double() - ref).abs().max().item() / sc < 3e-6
+    assert e2 <= 1.1 * e0, (e2, e0)
+    p.tile = 64128
+    assert lib.ssdhip_conv2d_nhwc(ctypes.byref(p), st) == _lib.EINVAL
+    p.tile, p.rows_per_img = 128128, 0
+    assert lib.ssdhip_conv2d_nhwc(ctypes.byref(p), st) == _lib.EINVAL

@@ -568,7 +568,7 @@ def test_pool_fusion_is_bit_identical(env, monkeypatch):
 
 
 @pytest.mark.parametrize('switches', [dict(SSD_NO_FUSED_WINOGRAD='1'), dict(SSD_NO_FUSED_WINOGRAD='1', SSD_WINOGRAD='f2'), dict(SSD_NO_PLANE_QUEUE='1'),
-                                      dict(SSD_NO_SPLITK='1', SSD_NO_POOL_FUSE='1')])
+                                      dict(SSD_NO_SPLITK='1', SSD_NO_POOL_FUSE='1'), dict(SSD_PLANE_GEMM='bf16x3')])
 def test_fallback_routes_run_the_same_network(env, golden, monkeypatch, switches):
     """The kernels the default route no longer launches stay part of the product (A/B switches, other shapes): conv_c64 for conv_1_2 /
     conv_2_1 and the three-pass Winograd forms for the wide maps (SSD_NO_FUSED_WINOGRAD), the one-slot-per-block plane GEMM
