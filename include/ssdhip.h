@@ -80,7 +80,7 @@ typedef struct {
     int32_t compute;        /* 0: exact fp32 MFMA (default, the headline path); 1: operands rounded to bf16 at LDS staging,
                                v_mfma_f32_32x32x16_bf16 with fp32 accumulate (BASELINE configs[3]); tensors stay fp32 in HBM;
                                2 (opt-in, 128 x 128 plane GEMMs only): every fp32 operand as three bf16 terms, the six products down to
-                               2^-24 on the bf16 MFMA with fp32 accumulate -- error vs fp64 no larger than mode 0, 1.3x its speed */
+                               2^-24 on the bf16 MFMA with fp32 accumulate -- error vs fp64 no larger than mode 0, 1.45x its speed */
     float* ws;              /* NULL, or split-K workspace of ws_bytes bytes (ssdhip_conv2d_ws_bytes): launches whose tile grid cannot
                                fill the chip (tiny maps) split K over blocks and sum the partial tiles in a second, fixed-order pass */
     int64_t ws_bytes;

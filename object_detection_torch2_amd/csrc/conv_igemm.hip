@@ -22,6 +22,7 @@
 //               (row >> 2) & 3) and the products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulators (one ds_read_b128 = the
 //               8 k of one MFMA operand); epilogue, BN statistics and every tensor in HBM stay fp32
 #include "common.h"
+#include <stdlib.h>
 
 // gemm_planes.hip: LDS-DMA staged plane GEMM (Winograd domain)
 long long ssdhip_gemm_planes_queue_ws_bytes(void);
@@ -658,7 +659,8 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
         // 128 x 128 tiles at K >= 256 with a caller workspace: the persistent work-queue kernel (no tile quantisation, one pipeline fill per
         // launch; gemm_planes.hip).  Without a workspace (and for every other tile): the one-launch-slot-per-block kernel below.
         if (p->compute == 2) {
-            int rc = ssdhip_gemm_planes_dma(p->x, p->w, p->y, a.M, p->Cin, p->Cout, p->rows_per_img, p->w_img_stride, BM, BN, a.tpb, (hipStream_t)stream, 100);
+            static const bool nw8 = getenv("SSDHIP_SPLIT_NW") && atoi(getenv("SSDHIP_SPLIT_NW")) == 8;      // A/B of the two wave layouts (probe scripts)
+            int rc = ssdhip_gemm_planes_dma(p->x, p->w, p->y, a.M, p->Cin, p->Cout, p->rows_per_img, p->w_img_stride, BM, BN, a.tpb, (hipStream_t)stream, nw8 ? 101 : 100);
             if (rc != SSDHIP_OK) { ssdhip_set_error("conv2d: split-bf16 plane GEMM needs 128 x 128 tiles"); return rc; }
             SSDHIP_CHECK_LAUNCH();
             return SSDHIP_OK;

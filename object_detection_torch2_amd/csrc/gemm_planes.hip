@@ -220,8 +220,11 @@ __device__ __forceinline__ void pl_split8(const f32x4& lo, const f32x4& hi, pl_b
     for (int i = 0; i < 3; ++i) t[i] = __builtin_bit_cast(pl_bf16x8, u[i]);
 }
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_planes_split_kernel(PlaneArgs a) {
-    constexpr int BM = 128, BN = 128, WNC = 4, RPP = 64, WROWS = 64, WCOLS = 32, MT = 2, AL = 2, BL = 2;
+// NW = 8: 2 x 4 waves of 64 x 32 (two blocks per CU); NW = 4: 2 x 2 waves of 64 x 64 -- a value of A is then split by two waves instead of four
+// and a value of B serves two m-tiles AND two n-tiles: 32 splits per 24 MFMAs instead of 24 per 12 (the form is bound by the split's VALU work)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, NW == 8 ? 4 : 2))) void gemm_planes_split_kernel(PlaneArgs a) {
+    constexpr int BM = 128, BN = 128, WNC = NW / 2, RPP = 8 * NW, WROWS = 64, WCOLS = BN / WNC, MT = 2, NT = WCOLS / 32, AL = BM / RPP, BL = BN / RPP;
     __shared__ __attribute__((aligned(1024))) float lds[2 * (BM + BN) * LROW];
     float* As = lds;
     float* Bs = lds + 2 * BM * LROW;
@@ -265,11 +268,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
         }
     };
-    f32x16 acc[MT];
+    f32x16 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     issue(0);
     __syncthreads();
     // bf16 MFMA operand: lane (row = lane & 31, kh = lane >> 5) supplies k = 16 m + 8 kh .. + 7 of its row = the logical 16-B chunks
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int g = 0; g < total; ++g) {
         const int buf = g & 1;
         const unsigned ab = a_lds + (unsigned)(buf * BM * LROW * 4), bb = b_lds + (unsigned)(buf * BN * LROW * 4);
-        f32x4 fa[2][MT][2], fb[2][2];              // [k16 half][m-tile][low / high 16 B]
+        f32x4 fa[2][MT][2], fb[2][NT][2];          // [k16 half][m- / n-tile][low / high 16 B]
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -294,39 +299,54 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 for (int h = 0; h < 2; ++h)
                     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[m][i][h]) : "v"(ab + fko[m][h]), "n"(i * 32 * LROW * 4));
 #pragma unroll
-            for (int h = 0; h < 2; ++h) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[m][h]) : "v"(bb + fko[m][h]));
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[m][j][h]) : "v"(bb + fko[m][h]), "n"(j * 32 * LROW * 4));
         }
         issue(buf ^ 1);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            if (m == 0) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fa[0][1][0]), "+v"(fa[0][1][1]), "+v"(fb[0][0]), "+v"(fb[0][1]));
-            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fa[1][1][0]), "+v"(fa[1][1][1]), "+v"(fb[1][0]), "+v"(fb[1][1]));
-            pl_bf16x8 ta[MT][3], tb[3];
+            // the reads of half m were issued before those of half m + 1: (MT + NT) * 2 newer ones may stay outstanding for m = 0
+            if constexpr (NT == 1) {
+                if (m == 0) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fa[0][1][0]), "+v"(fa[0][1][1]), "+v"(fb[0][0][0]), "+v"(fb[0][0][1]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fa[1][1][0]), "+v"(fa[1][1][1]), "+v"(fb[1][0][0]), "+v"(fb[1][0][1]));
+            } else {
+                if (m == 0) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fa[0][1][0]), "+v"(fa[0][1][1]), "+v"(fb[0][0][0]), "+v"(fb[0][0][1]), "+v"(fb[0][NT - 1][0]), "+v"(fb[0][NT - 1][1]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fa[1][1][0]), "+v"(fa[1][1][1]), "+v"(fb[1][0][0]), "+v"(fb[1][0][1]), "+v"(fb[1][NT - 1][0]), "+v"(fb[1][NT - 1][1]));
+            }
+            pl_bf16x8 ta[MT][3], tb[NT][3];
 #pragma unroll
             for (int i = 0; i < MT; ++i) pl_split8(fa[m][i][0], fa[m][i][1], ta[i]);
-            pl_split8(fb[m][0], fb[m][1], tb);
-            // small terms first: (a3 b1) (a2 b2) (a1 b3) (a2 b1) (a1 b2) (a1 b1)
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[i][2], tb[0], acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[i][1], tb[1], acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[i][0], tb[2], acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[i][1], tb[0], acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[i][0], tb[1], acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[i][0], tb[0], acc[i], 0, 0, 0);
-            }
-        }
-        if (++kt_in == KT) {
-            kt_in = 0;
-            const int co = n0 + wn * WCOLS + (lane & 31);
+            for (int j = 0; j < NT; ++j) pl_split8(fb[m][j][0], fb[m][j][1], tb[j]);
+            // small terms first: (a3 b1) (a2 b2) (a1 b3) (a2 b1) (a1 b2) (a1 b1)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = m_cur + wm * WROWS + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                    if (co < a.Cout) a.y[(size_t)m * a.Cout + co] = acc[i][e];
-                    acc[i][e] = 0.f;
+                for (int j = 0; j < NT; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[i][2], tb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[i][1], tb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[i][0], tb[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[i][1], tb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[i][0], tb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[i][0], tb[j][0], acc[i][j], 0, 0, 0);
                 }
+        }
+        if (++kt_in == KT) {
+            kt_in = 0;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int co = n0 + wn * WCOLS + j * 32 + (lane & 31);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int m = m_cur + wm * WROWS + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                        if (co < a.Cout) a.y[(size_t)m * a.Cout + co] = acc[i][j][e];
+                        acc[i][j][e] = 0.f;
+                    }
+            }
             m_cur += BM;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -635,7 +655,12 @@ int ssdhip_gemm_planes_dma(const float* v, const float* u, float* y, int M, int 
     dim3 grid(cdiv(a.MB, a.tpb) * a.NB), block(256);
     if (abl == 100) {          // compute = 2: the split-bf16 form (opt-in; 128 x 128 tiles only)
         if (BM != 128 || BN != 128) return SSDHIP_ENOSUP;
-        hipLaunchKernelGGL(gemm_planes_split_kernel, grid, dim3(512), 0, st, a);
+        hipLaunchKernelGGL(gemm_planes_split_kernel<4>, grid, dim3(256), 0, st, a);
+        return SSDHIP_OK;
+    }
+    if (abl == 101) {          // A/B: the 8-wave form of the same (scripts/plane_split_probe.py with SPLIT_NW=8)
+        if (BM != 128 || BN != 128) return SSDHIP_ENOSUP;
+        hipLaunchKernelGGL(gemm_planes_split_kernel<8>, grid, dim3(512), 0, st, a);
         return SSDHIP_OK;
     }
 #ifdef SSDHIP_PROBES      // libssdhip_probes.so only: A/B variants and timing-only ablations (abl 1 / 2 return wrong results by design)

@@ -117,7 +117,7 @@ class Engine:
         self._no_patch = os.environ.get('SSD_NO_BF16_PATCH') == '1'
         self._no_plane_queue = os.environ.get('SSD_NO_PLANE_QUEUE') == '1'      # A/B: every plane GEMM on the one-slot-per-block kernel
         # opt-in, never the default: 128 x 128 plane GEMMs as three bf16 terms per fp32 operand and six products on the bf16 MFMA (csrc/gemm_planes.hip:
-        # error vs fp64 no larger than the fp32 MFMA's, 1.3x its speed); the default keeps exact fp32 products, the reference's arithmetic
+        # error vs fp64 no larger than the fp32 MFMA's, 1.45x its speed); the default keeps exact fp32 products, the reference's arithmetic
         self._plane_split = os.environ.get('SSD_PLANE_GEMM', 'fp32') == 'bf16x3'
         if os.environ.get('SSD_PLANE_GEMM', 'fp32') not in ('fp32', 'bf16x3'):
             raise ValueError("SSD_PLANE_GEMM must be 'fp32' or 'bf16x3'")
