@@ -32,6 +32,7 @@ struct PlaneArgs {
     float* y;            // (planes * rows_per_plane, Cout)
     long long u_plane_stride;
     int M, K, KT, Cout, rows_per_plane, MB, NB, tpb;
+    long long u_term_stride;      // split-bf16 form with pre-split weights: elements between the three bf16 term images of U
 };
 
 template <int BM, int BN>
@@ -222,10 +223,15 @@ __device__ __forceinline__ void pl_split8(const f32x4& lo, const f32x4& hi, pl_b
 
 // NW = 8: 2 x 4 waves of 64 x 32 (two blocks per CU); NW = 4: 2 x 2 waves of 64 x 64 -- a value of A is then split by two waves instead of four
 // and a value of B serves two m-tiles AND two n-tiles: 32 splits per 24 MFMAs instead of 24 per 12 (the form is bound by the split's VALU work)
-template <int NW>
+// BPRE: the weights arrive PRE-SPLIT (ssdhip_split_bf16x3 of the fp32 planes U: three bf16 images, a.u_term_stride elements apart) -- they
+// change once per optimizer step (frozen layers: never), so their split does not belong in the K loop.  LDS then holds, per stage, the fp32
+// A tile (16 KiB) and three 64-B-row bf16 B tiles (24 KiB; 16-B chunks XOR-swizzled with (row >> 2) & 3: conflict-free ds_read_b128 for
+// the MFMA feed): 80 KiB per block, two blocks per CU.  Only A is split in registers: 88 VALU operations per 24 MFMAs instead of 176.
+template <int NW, bool BPRE = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, NW == 8 ? 4 : 2))) void gemm_planes_split_kernel(PlaneArgs a) {
     constexpr int BM = 128, BN = 128, WNC = NW / 2, RPP = 8 * NW, WROWS = 64, WCOLS = BN / WNC, MT = 2, NT = WCOLS / 32, AL = BM / RPP, BL = BN / RPP;
-    __shared__ __attribute__((aligned(1024))) float lds[2 * (BM + BN) * LROW];
+    constexpr int BSTAGE = BPRE ? 3 * BN * 16 : BN * LROW;          // floats of LDS per stage of B: three bf16 tiles of 64-B rows, or one fp32 tile
+    __shared__ __attribute__((aligned(1024))) float lds[2 * BM * LROW + 2 * BSTAGE];
     float* As = lds;
     float* Bs = lds + 2 * BM * LROW;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -249,20 +255,38 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, NW =
     float* a_dst = As + (8 * wave) * LROW;
     float* b_dst = Bs + (8 * wave) * LROW;
     int ld_kt = 0, ld_tile = 0;
-    const char* ub = reinterpret_cast<const char*>(a.u) + (size_t)(m0 / a.rows_per_plane) * (size_t)a.u_plane_stride * 4;
+    constexpr int ESZ = BPRE ? 2 : 4;                               // bytes per weight element
+    const char* ub = reinterpret_cast<const char*>(a.u) + (size_t)(m0 / a.rows_per_plane) * (size_t)a.u_plane_stride * ESZ;
+    // pre-split B: a wave-instruction lands 16 rows x 64 B; lane (row = lane >> 2, physical chunk = lane & 3) fetches the logical chunk
+    // (lane & 3) ^ ((row >> 2) & 3) of its row; wave w of pass i owns rows 16 (NW i + w) .. + 15
+    const int brow = lane >> 2;
+    const unsigned bsrc = (unsigned)(((lane & 3) ^ ((brow >> 2) & 3)) * 16);
+    const unsigned rowKb = (unsigned)a.K * 2u;
     auto issue = [&](int buf) {
         const unsigned kb = (unsigned)ld_kt * (BK * 4);
 #pragma unroll
         for (int i = 0; i < AL; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(vb + (a_off + (unsigned)(RPP * i) * rowK + kb)), (lptr_t)(a_dst + (buf * BM + RPP * i) * LROW), 16, 0, 0);
+        if constexpr (BPRE) {
+            const unsigned kb2 = (unsigned)ld_kt * (BK * 2);
 #pragma unroll
-        for (int i = 0; i < BL; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(ub + (b_off + (unsigned)(RPP * i) * rowK + kb)), (lptr_t)(b_dst + (buf * BN + RPP * i) * LROW), 16, 0, 0);
+            for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+                for (int i = 0; i < BN / (16 * NW); ++i) {
+                    const int r0 = 16 * (NW * i + wave);
+                    __builtin_amdgcn_global_load_lds((gptr_t)(ub + (size_t)t3 * (size_t)a.u_term_stride * 2 + ((unsigned)(n0 + r0 + brow) * rowKb + kb2 + bsrc)),
+                                                     (lptr_t)(Bs + buf * BSTAGE + (t3 * BN + r0) * 16), 16, 0, 0);
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < BL; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(ub + (b_off + (unsigned)(RPP * i) * rowK + kb)), (lptr_t)(b_dst + (buf * BN + RPP * i) * LROW), 16, 0, 0);
+        }
         if (++ld_kt == KT) {
             if (ld_tile + 1 < ntl) {
                 ld_kt = 0; ++ld_tile;
                 a_off += (unsigned)BM * rowK;
-                ub = reinterpret_cast<const char*>(a.u) + (size_t)((m0 + ld_tile * BM) / a.rows_per_plane) * (size_t)a.u_plane_stride * 4;
+                ub = reinterpret_cast<const char*>(a.u) + (size_t)((m0 + ld_tile * BM) / a.rows_per_plane) * (size_t)a.u_plane_stride * ESZ;
             } else {
                 ld_kt = KT - 1;
             }
@@ -284,13 +308,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, NW =
 #pragma unroll
     for (int m = 0; m < 2; ++m) { fko[m][0] = (unsigned)(((4 * m + 2 * kh) ^ fx) * 16); fko[m][1] = (unsigned)(((4 * m + 2 * kh + 1) ^ fx) * 16); }
     const unsigned a_lds = (unsigned)(uintptr_t)(lptr_t)(As + (wm * WROWS + frow) * LROW);
-    const unsigned b_lds = (unsigned)(uintptr_t)(lptr_t)(Bs + (wn * WCOLS + frow) * LROW);
+    const unsigned b_lds = BPRE ? (unsigned)(uintptr_t)(lptr_t)(Bs + (wn * WCOLS + frow) * 16) : (unsigned)(uintptr_t)(lptr_t)(Bs + (wn * WCOLS + frow) * LROW);
+    // pre-split B fragment: lane (row, kh) reads the 16 B = k 16 m + 8 kh .. + 7 of term t3: logical chunk 2 m + kh of its 64-B row
+    unsigned fkb[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) fkb[m] = (unsigned)(((2 * m + kh) ^ ((frow >> 2) & 3)) * 16);
     const int total = ntl * KT;
     int kt_in = 0, m_cur = m0;
     for (int g = 0; g < total; ++g) {
         const int buf = g & 1;
-        const unsigned ab = a_lds + (unsigned)(buf * BM * LROW * 4), bb = b_lds + (unsigned)(buf * BN * LROW * 4);
-        f32x4 fa[2][MT][2], fb[2][NT][2];          // [k16 half][m- / n-tile][low / high 16 B]
+        const unsigned ab = a_lds + (unsigned)(buf * BM * LROW * 4), bb = b_lds + (unsigned)(buf * BSTAGE * 4);
+        f32x4 fa[2][MT][2], fb[2][NT][BPRE ? 3 : 2];          // [k16 half][m- / n-tile][low / high 16 B of fp32, or the three bf16 terms]
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -299,16 +327,28 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, NW =
                 for (int h = 0; h < 2; ++h)
                     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[m][i][h]) : "v"(ab + fko[m][h]), "n"(i * 32 * LROW * 4));
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
+            for (int j = 0; j < NT; ++j) {
+                if constexpr (BPRE) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[m][j][h]) : "v"(bb + fko[m][h]), "n"(j * 32 * LROW * 4));
+                    for (int t3 = 0; t3 < 3; ++t3)
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[m][j][t3]) : "v"(bb + fkb[m]), "n"((t3 * BN + j * 32) * 64));
+                } else {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[m][j][h]) : "v"(bb + fko[m][h]), "n"(j * 32 * LROW * 4));
+                }
+            }
         }
         issue(buf ^ 1);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             // the reads of half m were issued before those of half m + 1: (MT + NT) * 2 newer ones may stay outstanding for m = 0
-            if constexpr (NT == 1) {
+            if constexpr (BPRE) {
+                static_assert(!BPRE || NT == 2, "pre-split B is wired for the 2 x 2 wave layout");
+                // per half m: MT * 2 + NT * 3 = 10 reads; those of half 1 may stay outstanding while half 0 is consumed
+                if (m == 0) asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fa[0][1][0]), "+v"(fa[0][1][1]), "+v"(fb[0][0][0]), "+v"(fb[0][0][1]), "+v"(fb[0][0][2]), "+v"(fb[0][1][0]), "+v"(fb[0][1][1]), "+v"(fb[0][1][2]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fa[1][1][0]), "+v"(fa[1][1][1]), "+v"(fb[1][0][0]), "+v"(fb[1][0][1]), "+v"(fb[1][0][2]), "+v"(fb[1][1][0]), "+v"(fb[1][1][1]), "+v"(fb[1][1][2]));
+            } else if constexpr (NT == 1) {
                 if (m == 0) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fa[0][1][0]), "+v"(fa[0][1][1]), "+v"(fb[0][0][0]), "+v"(fb[0][0][1]));
                 else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fa[1][1][0]), "+v"(fa[1][1][1]), "+v"(fb[1][0][0]), "+v"(fb[1][0][1]));
             } else {
@@ -319,7 +359,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, NW =
 #pragma unroll
             for (int i = 0; i < MT; ++i) pl_split8(fa[m][i][0], fa[m][i][1], ta[i]);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) pl_split8(fb[m][j][0], fb[m][j][1], tb[j]);
+            for (int j = 0; j < NT; ++j) {
+                if constexpr (BPRE) {
+#pragma unroll
+                    for (int t3 = 0; t3 < 3; ++t3) tb[j][t3] = __builtin_bit_cast(pl_bf16x8, fb[m][j][t3]);
+                } else {
+                    pl_split8(fb[m][j][0], fb[m][j][1], tb[j]);
+                }
+            }
             // small terms first: (a3 b1) (a2 b2) (a1 b3) (a2 b1) (a1 b2) (a1 b1)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -351,6 +398,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, NW =
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+    }
+}
+
+// fp32 array -> its three bf16 term images (dst: 3 x n bf16, term-major): x = t1 + t2 + t3 exactly
+__global__ void split_bf16x3_kernel(const float2* __restrict__ src, unsigned* __restrict__ dst, long long n2) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
+        const float2 v = src[i];
+        unsigned t1, t2, t3;
+        pl_split(v.x, v.y, t1, t2, t3);
+        dst[i] = t1; dst[n2 + i] = t2; dst[2 * n2 + i] = t3;
     }
 }
 
@@ -624,6 +681,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }  // namespace
 
 // called from ssdhip_conv2d_nhwc (conv_igemm.hip) for plane GEMMs
+#ifdef SSDHIP_PROBES
+// libssdhip_probes.so only (scripts/plane_split_probe.py): the split-bf16 plane GEMM with PRE-SPLIT weights.  u3 = the three bf16 term images of the
+// weight planes (ssdhip_probe_split_bf16x3), u_term_stride elements apart; M = all rows of V (planes x rows_per_plane, a multiple of 128).
+extern "C" int ssdhip_probe_plane_gemm_bpre(const float* v, const void* u3, float* y, int M, int K, int Cout, int rows_per_plane,
+                                            long long u_plane_stride, long long u_term_stride, int tpb, void* stream) {
+    SSDHIP_REQUIRE(v && u3 && y && M > 0 && M % 128 == 0 && rows_per_plane % 128 == 0 && K >= 32 && K % 32 == 0 && Cout > 0 && tpb >= 1 &&
+                       (long long)M * K * 4 < (1ll << 31) && (long long)cdiv(Cout, 128) * 128 * K * 2 < (1ll << 31),
+                   "probe_plane_gemm_bpre: 128-row tiles, K a multiple of 32, 32-bit byte offsets inside V and inside one term image of a plane");
+    PlaneArgs a;
+    a.v = v; a.u = reinterpret_cast<const float*>(u3); a.y = y; a.u_plane_stride = u_plane_stride; a.u_term_stride = u_term_stride;
+    a.M = M; a.K = K; a.KT = K / BK; a.Cout = Cout; a.rows_per_plane = rows_per_plane;
+    a.MB = M / 128; a.NB = cdiv(Cout, 128); a.tpb = tpb;
+    hipLaunchKernelGGL((gemm_planes_split_kernel<4, true>), dim3(cdiv(a.MB, a.tpb) * a.NB), dim3(256), 0, (hipStream_t)stream, a);
+    SSDHIP_CHECK_LAUNCH();
+    return SSDHIP_OK;
+}
+
+extern "C" int ssdhip_probe_split_bf16x3(const float* src, void* dst3, long long n, void* stream) {
+    SSDHIP_REQUIRE(src && dst3 && n > 0 && n % 2 == 0, "split_bf16x3: null pointer or odd element count");
+    long long blocks = (n / 2 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float2*>(src),
+                       reinterpret_cast<unsigned*>(dst3), n / 2);
+    SSDHIP_CHECK_LAUNCH();
+    return SSDHIP_OK;
+}
+#endif
+
 // Workspace of the work-queue form: control words + one 128 x 128 partial tile per block slot.
 long long ssdhip_gemm_planes_queue_ws_bytes(void) {
     const int S = ssdhip_cu_count() * 2 / 8;

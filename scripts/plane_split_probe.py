@@ -1,6 +1,7 @@
 """The opt-in split-bf16 form of the 128 x 128 plane GEMM (compute = 2: fp32 operands split in registers into three bf16 terms, six
 products on the bf16 MFMA, fp32 accumulation) against the exact-fp32 MFMA kernels on the same planes: time and error vs fp64."""
 import ctypes, os, sys
+os.environ.setdefault('SSDHIP_PROBES', '1')     # the pre-split-weights form exists in the probe build only (make -C object_detection_torch2_amd/csrc probes)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from object_detection_torch2_amd import _lib
@@ -35,8 +36,22 @@ for name, tp, cin, cout in SHAPES:
     t0 = timed(lambda: _lib.check(lib.ssdhip_conv2d_nhwc(ctypes.byref(p), st), 'gemm fp32'))
     p.y, p.compute, p.ws, p.ws_bytes = M2.data_ptr(), 2, None, 0
     t2 = timed(lambda: _lib.check(lib.ssdhip_conv2d_nhwc(ctypes.byref(p), st), 'gemm split'))
+    # pre-split weights (probe build): three bf16 term images of U made once, only V is split in the K loop
+    t3s, M3 = {}, torch.full((36 * tp * cout,), float('nan'), device=dev)
+    if hasattr(lib, 'ssdhip_probe_plane_gemm_bpre'):
+        U3 = torch.empty(3 * U.numel(), dtype=torch.bfloat16, device=dev)
+        _lib.check(lib.ssdhip_probe_split_bf16x3(ctypes.c_void_p(U.data_ptr()), ctypes.c_void_p(U3.data_ptr()), ctypes.c_longlong(U.numel()), st), 'split U')
+        for tpb in (1, 2, 3):
+            t3s[tpb] = timed(lambda: _lib.check(lib.ssdhip_probe_plane_gemm_bpre(ctypes.c_void_p(V.data_ptr()), ctypes.c_void_p(U3.data_ptr()), ctypes.c_void_p(M3.data_ptr()),
+                36 * tp, cin, cout, tp, ctypes.c_longlong(rows_pad * cin), ctypes.c_longlong(U.numel()), tpb, st), 'gemm bpre'))
     torch.cuda.synchronize()
     assert torch.isfinite(M2).all()
+    if t3s:
+        assert torch.isfinite(M3).all()
+        d = (M3 - M2).abs().max().item()
+        tb = min(t3s.values())
+        print(f'{name}: pre-split weights: ' + ' '.join(f'tpb {k}: {v:7.1f} us' for k, v in t3s.items()) + f'  best {2.0 * 36 * tp * cin * cout / tb / 1e6:6.1f} TF-equivalent; '
+              f'max |M - M(split in registers)| = {d:.3e} (same terms, same order: expected 0)', flush=True)
     errs = []
     for pl, r0 in ((0, 0), (7, 64), (35, tp - 128)):
         ref = V.view(36, tp, cin)[pl, r0:r0 + 128].double() @ U.view(36, rows_pad, cin)[pl, :cout].double().t()
