@@ -159,7 +159,9 @@ def ptr(t):
 
 
 def stream():
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    # the raw handle of torch's current stream on the current device; torch.cuda.current_stream() builds a Stream object and resolves the
+    # device index on every call (~8 us of host time, ~110 calls per training step)
+    return c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def require_gpu(*tensors):
