@@ -6,9 +6,11 @@
 //   S  wave = 16 tiles x 16 channels x 36 planes (2 x 4 waves):           one ds_read_b32 of A and one of B per MFMA
 //   P  wave = 16 tiles x 32 channels x 18 planes (2 plane halves x 2 x 2): one ds_read_b32 of A and one ds_read_b64 of B per two MFMAs
 //      (the real kernel would exchange half an output transform between the plane halves through LDS at the end of an item)
-// Operand images per K-step (BK = 4: 36 planes x 32 tiles x 16 B + 36 planes x 64 channels x 16 B = 54 KiB, double-buffered: 108 KiB of LDS,
-// one block of 8 waves per CU) arrive by LDS-DMA from contiguous, pre-packed global images; the A images stream from HBM (one region per
-// block and K-step), the B images are shared by all blocks (L2-resident weights).
+// Operand images per K-step (BK = 4: A = 36 planes x 32 tiles x 16 B = 18 KiB, B = 36 planes x 64 channels x 16 B = 36 KiB; B double-buffered,
+// A in a ring of NA = 2 .. 4 stages: 108 .. 144 KiB of LDS, one block of 8 waves per CU) arrive by LDS-DMA from contiguous, pre-packed global
+// images; the A images stream from HBM (one region per block and K-step), the B images are shared by all blocks (L2-resident weights).
+// Measured (profiles/r04_j_*): the inner loop alone 0.78-0.85 of the fp32 MFMA peak, with the operand stream 0.55-0.60 -- the item the
+// accumulators allow (32 x 64) needs 54 KiB of operands per 2,304 MFMA cycles and CU, three times the plane GEMM's bytes per flop.
 //   hipcc --offload-arch=gfx950 -O3 f4_fused_gemm_probe.hip -o f4_fused_gemm_probe && ./f4_fused_gemm_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -32,7 +34,7 @@ constexpr int STAGE = A_BYTES + B_BYTES;          // 55,296
 constexpr int PIECES = STAGE / 1024;              // 54 wave-instructions of 1 KiB per K-step
 
 // MODE 0 = S, 1 = P;  ABL bit 0: no DMA in the loop, bit 1: no epilogue stores
-template <int MODE, int ABL, int DEPTH>
+template <int MODE, int ABL, int DEPTH, int NA = 2>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void probe(const char* __restrict__ asrc, const char* __restrict__ bsrc,
                                                                                          float* __restrict__ out, int KT, int items) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -44,30 +46,36 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     else { ph = wave >> 2; wm = (wave >> 1) & 1; wn = wave & 1; }
     const int li = lane & 15, kq = lane >> 4;
     // fragment addresses inside a stage
+    // LDS: NA stages of the A image (streamed from HBM, requested NA - 1 K-steps ahead), then 2 stages of the B image (weights from L2, one ahead)
     const unsigned a_rd = lds0 + (unsigned)(((ph * PW * TILES + 16 * wm + li) * BK + kq) * 4);
-    const unsigned b_rd = lds0 + (unsigned)A_BYTES +
+    const unsigned b_rd = lds0 + (unsigned)(NA * A_BYTES) +
                           (MODE == 0 ? (unsigned)(((16 * wn + li) * BK + kq) * 4) : (unsigned)(((ph * PW * 2 + wn) * 16 * BK * 2 + (li * BK + kq) * 2) * 4));
     constexpr int A_PSTRIDE = TILES * BK * 4, B_PSTRIDE = CH * BK * 4;
 
     const char* ablk = asrc + (size_t)blockIdx.x * (size_t)items * KT * A_BYTES;
-    int ld_step = 0;
     const int total = items * KT;
-    auto issue = [&](int buf) {
-        const char* as = ablk + (size_t)ld_step * A_BYTES;
-        const char* bs = bsrc + (size_t)(ld_step % KT) * B_BYTES;
+    constexpr int APIECES = A_BYTES / 1024, BPIECES = B_BYTES / 1024;       // 18, 36
+    auto issue_a = [&](int step) {            // A image of K-step `step` -> ring slot step % NA
+        const int st = step < total ? step : total - 1;
+        const char* as = ablk + (size_t)st * A_BYTES;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            const int piece = wave + 8 * k;                     // 0 .. 55; 54 exist
-            if (piece < PIECES) {
-                const char* src = piece < A_BYTES / 1024 ? as + piece * 1024 : bs + (piece - A_BYTES / 1024) * 1024;
-                __builtin_amdgcn_global_load_lds((gptr_t)(src + lane * 16), (lptr_t)(lds + buf * STAGE + piece * 1024), 16, 0, 0);
-            }
+        for (int k = 0; k < 3; ++k) {
+            const int piece = wave + 8 * k;
+            if (piece < APIECES) __builtin_amdgcn_global_load_lds((gptr_t)(as + piece * 1024 + lane * 16), (lptr_t)(lds + (step % NA) * A_BYTES + piece * 1024), 16, 0, 0);
         }
-        if (ld_step + 1 < total) ++ld_step;
+    };
+    auto issue_b = [&](int step) {
+        const char* bs = bsrc + (size_t)(step % KT) * B_BYTES;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int piece = wave + 8 * k;
+            if (piece < BPIECES) __builtin_amdgcn_global_load_lds((gptr_t)(bs + piece * 1024 + lane * 16), (lptr_t)(lds + NA * A_BYTES + (step & 1) * B_BYTES + piece * 1024), 16, 0, 0);
+        }
     };
 
     f32x4 acc[PW][NT];
-    issue(0);
+    issue_b(0);
+    for (int k = 0; k < NA - 1; ++k) issue_a(k);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int g = 0;
@@ -78,7 +86,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int j = 0; j < NT; ++j) acc[p][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int kt = 0; kt < KT; ++kt, ++g) {
             const int buf = g & 1;
-            const unsigned ab = a_rd + (unsigned)(buf * STAGE), bb = b_rd + (unsigned)(buf * STAGE);
+            const unsigned ab = a_rd + (unsigned)((g % NA) * A_BYTES), bb = b_rd + (unsigned)(buf * B_BYTES);
             // fragments are requested D planes ahead of their MFMAs (ring of D + 1 registers)
             constexpr int D = DEPTH, R = D + 1;
             float fa[R], fs[R];
@@ -91,7 +99,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     } while (0)
 #pragma unroll
             for (int p = 0; p < D; ++p) F4_REQ(p);
-            if (!(ABL & 1)) issue(buf ^ 1);
+            if (!(ABL & 1)) { issue_b(g + 1); issue_a(g + NA - 1); }      // the slot of step g - 1 is free: its readers passed the last barrier
 #pragma unroll
             for (int p = 0; p < PW; ++p) {
                 const int r = p % R;
@@ -109,7 +117,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 __builtin_amdgcn_sched_barrier(0);
             }
 #undef F4_REQ
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // B of step g + 1 and A of step g + 1 (requested NA - 2 steps ago) must have landed; this step's A request (the newest: 3 pieces on
+            // waves 0 and 1, 2 on the others) may stay in flight when NA > 2
+            if (NA == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (wave < 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
         // stand-in epilogue: 16 output pixels per tile and channel group from sums of planes (the real A^T m A is ~10 operations per output),
@@ -139,16 +151,16 @@ __global__ void fill(float* p, size_t n) {
     }
 }
 
-template <int MODE, int ABL, int DEPTH>
+template <int MODE, int ABL, int DEPTH, int NA = 2>
 static void run(const char* name, const char* a, const char* b, float* out, int KT, int items, int grid) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(probe<MODE, ABL, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(probe<MODE, ABL, DEPTH, NA>), hipFuncAttributeMaxDynamicSharedMemorySize, NA * A_BYTES + 2 * B_BYTES);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((probe<MODE, ABL, DEPTH>), dim3(grid), dim3(512), 2 * STAGE, 0, a, b, out, KT, items);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((probe<MODE, ABL, DEPTH, NA>), dim3(grid), dim3(512), NA * A_BYTES + 2 * B_BYTES, 0, a, b, out, KT, items);
     hipDeviceSynchronize();
     const int reps = 10;
     hipEventRecord(e0);
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((probe<MODE, ABL, DEPTH>), dim3(grid), dim3(512), 2 * STAGE, 0, a, b, out, KT, items);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((probe<MODE, ABL, DEPTH, NA>), dim3(grid), dim3(512), NA * A_BYTES + 2 * B_BYTES, 0, a, b, out, KT, items);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     if (hipGetLastError() != hipSuccess) { printf("%s: launch failed\n", name); return; }
@@ -172,10 +184,14 @@ int main() {
         run<0, 0, 1>("S: 16x16 waves, 36 planes, 1 plane ahead", a, b, out, KT, items, grid);
         run<0, 0, 2>("S, 2 planes ahead", a, b, out, KT, items, grid);
         run<0, 0, 3>("S, 3 planes ahead", a, b, out, KT, items, grid);
+        run<0, 0, 2, 3>("S, 2 ahead, A image requested 2 K-steps ahead", a, b, out, KT, items, grid);
+        run<0, 0, 2, 4>("S, 2 ahead, A image requested 3 K-steps ahead", a, b, out, KT, items, grid);
+        run<0, 0, 3, 4>("S, 3 ahead, A image requested 3 K-steps ahead", a, b, out, KT, items, grid);
         run<0, 1, 2>("S, 2 ahead, no DMA in the loop", a, b, out, KT, items, grid);
         run<0, 3, 2>("S, 2 ahead, no DMA, no epilogue stores", a, b, out, KT, items, grid);
         run<1, 0, 1>("P: 16x32 waves, 18 planes per half, 1 ahead", a, b, out, KT, items, grid);
         run<1, 0, 2>("P, 2 planes ahead", a, b, out, KT, items, grid);
+        run<1, 0, 2, 4>("P, 2 ahead, A image requested 3 K-steps ahead", a, b, out, KT, items, grid);
         run<1, 1, 2>("P, 2 ahead, no DMA in the loop", a, b, out, KT, items, grid);
         run<1, 3, 2>("P, 2 ahead, no DMA, no epilogue stores", a, b, out, KT, items, grid);
         hipFree(a); hipFree(b); hipFree(out);
