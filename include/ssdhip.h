@@ -138,6 +138,23 @@ int ssdhip_winograd4_weight_adjoint(const float* w_oihw, float* U, int Cout, int
 int ssdhip_winograd4_output_head(const float* M, const float* bias, float* y, int64_t y_batch_stride, int N, int H, int W, int Cout,
                                  int Cp, int Tp, void* stream);
 
+/* ---- A3, opt-in: the same F(4x4,3x3) convolution in TWO passes for maps too large for the three-pass form (the 150 / 75 px layers
+ * conv_2_1 .. conv_3_1 of model/vgg16.py:33): the products M never reach memory.  Cin % 32 == 0, Cout % 64 == 0.
+ *   pack:   U (36, rows_pad, Cin) of ssdhip_winograd4_weight (KP = Cin) -> upk (36 * Cout * Cin floats), the per-K-step LDS images
+ *   input:  x (N,H,W,C) -> vb (ssdhip_wino4f_v_floats floats): V = B^T d B in K-step-blocked tiles of 32; producer BN.ReLU fused on load
+ *   gemm:   vb, upk -> z (N,H,W,Cout) = A^T (sum_c V U) A + bias and BN partial sums (ssdhip_wino4f_tile_blocks rows, Cout, 2; stats may be
+ *           NULL); returns the number of partial rows.  _pool: even H, W; stores per 2x2 / stride 2 pooling window the maximum and the
+ *           minimum of z, (N, H/2, W/2, Cout) each, instead of z (as ssdhip_wino_fused_conv_pool; consumer: ssdhip_bn_relu_select)
+ * csrc/wino4_fused.hip; same arithmetic as the three-pass form up to the summation order of the GEMM.                                   */
+int ssdhip_wino4f_tile_blocks(int N, int H, int W);
+int64_t ssdhip_wino4f_v_floats(int N, int H, int W, int Cin);
+int ssdhip_wino4f_pack(const float* U, float* upk, int Cout, int Cin, int rows_pad, void* stream);
+int ssdhip_wino4f_input(const float* x, const float* in_scale, const float* in_shift, float* vb, int N, int H, int W, int C, void* stream);
+int ssdhip_wino4f_gemm(const float* vb, const float* upk, const float* bias, float* z, float* stats, int N, int H, int W, int Cin, int Cout,
+                       void* stream);
+int ssdhip_wino4f_gemm_pool(const float* vb, const float* upk, const float* bias, float* zmax, float* zmin, float* stats, int N, int H, int W,
+                            int Cin, int Cout, void* stream);
+
 /* ---- A4  nn.BatchNorm2d, training=True (model/vgg16.py:34, model/ssd.py:62) -----------------------------
  * partial (MB,C,2) -> scale = gamma*rsqrt(var+eps), shift = beta-mean*scale (biased var); running stats EMA with
  * momentum and unbiased var, exactly nn.BatchNorm2d; save_mean/save_invstd (C) for backward (may be NULL).

@@ -119,6 +119,12 @@ SIGNATURES = {
     'ssdhip_relu_dropout': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, ctypes.c_uint32, c_int, c_void_p]),
     'ssdhip_log_softmax_dot_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     'ssdhip_log_softmax_dot_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'ssdhip_wino4f_tile_blocks': (c_int, [c_int, c_int, c_int]),
+    'ssdhip_wino4f_v_floats': (c_int64, [c_int, c_int, c_int, c_int]),
+    'ssdhip_wino4f_pack': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'ssdhip_wino4f_input': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'ssdhip_wino4f_gemm': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'ssdhip_wino4f_gemm_pool': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ssdhip_augment_row_floats': (c_int, []),
     'ssdhip_augment_ws_bytes': (c_int64, [c_int]),
     'ssdhip_augment_batch': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -129,6 +129,7 @@ class Engine:
             raise ValueError(f"SSD_WINOGRAD must be 'f2' or 'f4', got {self._wino_mode!r}")
         self._pool_fuse = os.environ.get('SSD_NO_POOL_FUSE') != '1'      # A/B: conv + 2x2 max-pool without materialising z (conv_1_2, conv_2_2)
         self._w4_max_map = int(os.environ.get('SSD_W4_MAX_MAP', '160'))     # largest map side on the F(4x4) passes (SSD512: conv_3_2 / conv_3_3 at 128 px)
+        self._early_f4 = os.environ.get('SSD_EARLY_F4', '0') == '1'       # opt-in: conv_2_2 / conv_3_1 on the two-pass F(4x4) form (csrc/wino4_fused.hip)
         self._w4_min_cin = int(os.environ.get('SSD_W4_MIN_CIN', '256'))      # A/B: 128 also routes conv_3_1 (K = 128) to the F(4x4) passes
         self._cus = None       # compute units of the device (first forward): the persistent backbone grids take 7/8 of them beside the tail
         self._wf_blocks_env = os.environ.get('SSD_WF_BLOCKS')
@@ -759,11 +760,34 @@ class Engine:
                     # maxima and minima of z instead of z, the pool pass becomes a select over a quarter-size pair (bit-identical result)
                     pool_fused = (self._pool_fuse and c.frozen and s.pool_pad == 0 and s.head is None and not nxt_patch
                                   and g['ho'] % 2 == 0 and g['wo'] % 2 == 0)
+                    # opt-in (SSD_EARLY_F4=1): the K = 128 layers among these (conv_2_2, conv_3_1) through the two-pass F(4x4) form
+                    # (csrc/wino4_fused.hip): 0.90 vs 0.99 and 0.42 vs 0.49 ms per layer (scripts/w4f_bench.py), at F(4x4)'s 2.7x rounding error
+                    early_f4 = self._early_f4 and c.frozen and c.cin >= 128 and c.cin % 32 == 0 and c.cout % 64 == 0 and not self.bf16
                     if pool_fused:
                         zmm = b.setdefault('zmm', {}).get(i)
                         if zmm is None:
                             zmm = torch.empty(2, N, g['ha'], g['wa'], c.cout, device=dev, dtype=torch.float32)
                             b['zmm'][i] = zmm
+                    if early_f4:
+                        if getattr(c, 'w4f_img', None) is None or c.w4f_img.device != w1.device or c.w4f_key != key:
+                            from .. import ops
+                            c.w4f_img, c.w4f_key = ops.wino4f_pack(w1), key
+                        need = _lib.check(self.lib.ssdhip_wino4f_v_floats(N, g['hi'], g['wi'], c.cin), 'wino4f_v_floats')
+                        vb = b.get('w4f_vb')
+                        if vb is None or vb.numel() < need:
+                            vb = b['w4f_vb'] = torch.empty(need, device=dev, dtype=torch.float32)
+                        _lib.check(self.lib.ssdhip_wino4f_input(_lib.ptr(cur), _lib.ptr(cur_xs[0]) if cur_xs is not None else None,
+                                                                _lib.ptr(cur_xs[1]) if cur_xs is not None else None, _lib.ptr(vb), N, g['hi'], g['wi'],
+                                                                c.cin, st), f'wino4f_input {c.name}')
+                        if pool_fused:
+                            rows = _lib.check(self.lib.ssdhip_wino4f_gemm_pool(_lib.ptr(vb), _lib.ptr(c.w4f_img), _lib.ptr(b1) if b1 is not None else None,
+                                                                               _lib.ptr(zmm[0]), _lib.ptr(zmm[1]), _lib.ptr(ws['partial']) if training else None,
+                                                                               N, g['hi'], g['wi'], c.cin, c.cout, st), f'conv2d {c.name}')
+                        else:
+                            rows = _lib.check(self.lib.ssdhip_wino4f_gemm(_lib.ptr(vb), _lib.ptr(c.w4f_img), _lib.ptr(b1) if b1 is not None else None,
+                                                                          _lib.ptr(z), _lib.ptr(ws['partial']) if training else None,
+                                                                          N, g['hi'], g['wi'], c.cin, c.cout, st), f'conv2d {c.name}')
+                    elif pool_fused:
                         rows = _lib.check(self.lib.ssdhip_wino_fused_conv_pool(_lib.ptr(cur), _lib.ptr(c.wf_img), _lib.ptr(b1) if b1 is not None else None,
                                                                                _lib.ptr(cur_xs[0]) if cur_xs is not None else None,
                                                                                _lib.ptr(cur_xs[1]) if cur_xs is not None else None,
@@ -777,7 +801,12 @@ class Engine:
                                                                           _lib.ptr(ws['partial']) if training else None,
                                                                           _lib.ptr(self._wf_geo(b, N, g['hi'], g['wi'], dev)), N, g['hi'], g['wi'],
                                                                           c.cin, c.cout, self._wf_blocks, st), f'conv2d {c.name}')
-                    if self.prof is not None:
+                    if self.prof is not None and early_f4:
+                        e1.record()
+                        tiles = N * ((g['hi'] + 3) // 4) * ((g['wi'] + 3) // 4)
+                        self.prof.append(dict(layer=c.name + ' (two-pass F(4x4))', e0=e0, e1=e1, kernel='wino4f_input_kernel + wino4f_gemm_kernel',
+                                              flops=2.0 * 36 * tiles * c.cin * c.cout, direct_flops=2.0 * N * g['hi'] * g['wi'] * c.cin * c.cout * 9))
+                    elif self.prof is not None:
                         e1.record()
                         tiles = N * ((g['hi'] + 1) // 2) * ((g['wi'] + 1) // 2)
                         self.prof.append(dict(layer=c.name + ' (fused Winograd)', e0=e0, e1=e1,

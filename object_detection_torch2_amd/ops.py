@@ -437,6 +437,57 @@ def conv3x3_winograd4(x, w_oihw, bias=None, in_scale=None, in_shift=None, want_s
     return (z, stats, V) if return_v else (z, stats)
 
 
+def wino4f_pack(w_oihw):
+    """OIHW 3x3 weights -> the per-K-step LDS images of the two-pass F(4x4) form (csrc/wino4_fused.hip): U = G g G^T in fp64 (the
+    three-pass form's weight transform), then the blocked layout."""
+    _lib.require_gpu(w_oihw)
+    lib = _lib.load()
+    cout, cin, k, _ = w_oihw.shape
+    if k != 3 or cin % 32 or cout % 64:
+        raise ValueError('wino4f_pack: 3x3 kernels, Cin % 32 == 0, Cout % 64 == 0')
+    rows_pad = _rup(cout, 128)
+    U = torch.empty(36 * rows_pad * cin, device=w_oihw.device, dtype=torch.float32)
+    upk = torch.empty(36 * cout * cin, device=w_oihw.device, dtype=torch.float32)
+    st = _lib.stream()
+    _lib.check(lib.ssdhip_winograd4_weight(_lib.ptr(_lib.f32c(w_oihw)), _lib.ptr(U), cout, cin, rows_pad, cin, st), 'winograd4_weight')
+    _lib.check(lib.ssdhip_wino4f_pack(_lib.ptr(U), _lib.ptr(upk), cout, cin, rows_pad, st), 'wino4f_pack')
+    return upk
+
+
+def conv3x3_wino4f(x, w_oihw, bias=None, in_scale=None, in_shift=None, want_stats=False, upk=None, pool=False, vb=None):
+    """3x3 / stride 1 / pad 1 convolution through the two-pass Winograd F(4x4,3x3) form (csrc/wino4_fused.hip).  x (N,H,W,Cin) NHWC,
+    Cin % 32 == 0, Cout % 64 == 0.  Returns (z (N,H,W,Cout), stats (rows,Cout,2) or None); with pool=True (even H, W) the per-window
+    maxima and minima (zmax, zmin, stats) instead of z."""
+    _lib.require_gpu(x, w_oihw)
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    cout, cin, k, _ = w_oihw.shape
+    if k != 3 or cin != C or C % 32 or cout % 64:
+        raise ValueError('conv3x3_wino4f: 3x3 kernels, Cin % 32 == 0, Cout % 64 == 0')
+    dev = x.device
+    if upk is None:
+        upk = wino4f_pack(w_oihw)
+    need = _lib.check(lib.ssdhip_wino4f_v_floats(N, H, W, C), 'wino4f_v_floats')
+    if vb is None:
+        vb = torch.empty(need, device=dev, dtype=torch.float32)
+    assert vb.numel() >= need
+    st = _lib.stream()
+    _lib.check(lib.ssdhip_wino4f_input(_lib.ptr(x), _lib.ptr(in_scale), _lib.ptr(in_shift), _lib.ptr(vb), N, H, W, C, st), 'wino4f_input')
+    rows = _lib.check(lib.ssdhip_wino4f_tile_blocks(N, H, W), 'wino4f_tile_blocks')
+    stats = torch.empty(rows, cout, 2, device=dev, dtype=torch.float32) if want_stats else None
+    if pool:
+        zmax = torch.empty(N, H // 2, W // 2, cout, device=dev, dtype=torch.float32)
+        zmin = torch.empty_like(zmax)
+        got = _lib.check(lib.ssdhip_wino4f_gemm_pool(_lib.ptr(vb), _lib.ptr(upk), _lib.ptr(bias), _lib.ptr(zmax), _lib.ptr(zmin), _lib.ptr(stats),
+                                                      N, H, W, C, cout, st), 'wino4f_gemm_pool')
+        assert got == rows
+        return zmax, zmin, stats
+    z = torch.empty(N, H, W, cout, device=dev, dtype=torch.float32)
+    got = _lib.check(lib.ssdhip_wino4f_gemm(_lib.ptr(vb), _lib.ptr(upk), _lib.ptr(bias), _lib.ptr(z), _lib.ptr(stats), N, H, W, C, cout, st), 'wino4f_gemm')
+    assert got == rows
+    return z, stats
+
+
 def conv3x3_dgrad_winograd4(dy, w_oihw, accumulate_into=None):
     """Data gradient of a 3x3 / stride 1 / pad 1 convolution through the F(4x4,3x3) passes: the adjoint convolution of dy.
     dy (N,H,W,KP) with KP = Cout padded to a multiple of 32 (zero channels beyond Cout) -> dx (N,H,W,Cin)."""

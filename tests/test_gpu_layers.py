@@ -316,6 +316,45 @@ def test_conv3x3_winograd4(case):
     print(f'winograd4 {case}: max err / max |out| vs fp64 {e4:.2e}; F(2x2) {rel_err(z3.permute(0, 3, 1, 2).cpu().double(), ref64):.2e}; torch fp32 {rel_err(ref.double(), ref64):.2e}')
 
 
+@pytest.mark.parametrize('case', [(2, 38, 38, 64, 128), (1, 22, 30, 128, 64), (3, 9, 13, 32, 128), (1, 150, 150, 64, 64)])
+def test_conv3x3_wino4f_two_pass(case):
+    """Two-pass Winograd F(4x4,3x3) form (csrc/wino4_fused.hip: blocked input transform, then GEMM + output transform with all 36 planes in
+    accumulators) vs F.conv2d and vs the three-pass form on the same operands: fused BN+ReLU input, bias, BatchNorm partial sums, ragged
+    tile edges (sides not a multiple of 4), a partly filled last tile block, and the pooled form (window maxima / minima) on even maps."""
+    from object_detection_torch2_amd import ops
+    N, H, W, cin, cout = case
+    zprev = rnd(N, cin, H, W, seed=331)
+    scale, shift = rnd(cin, seed=332), rnd(cin, seed=333) + 0.5
+    w = rnd(cout, cin, 3, 3, seed=334, scale=(2.0 / (cin * 9)) ** 0.5)
+    b = rnd(cout, seed=335)
+    a = F.relu(zprev * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    ref = F.conv2d(a, w, b, padding=1)
+    ref64 = F.conv2d(a.double(), w.double(), b.double(), padding=1)
+    x = ops.to_nhwc(zprev.to(DEV))
+    z, stats = ops.conv3x3_wino4f(x, w.to(DEV), b.to(DEV), in_scale=scale.to(DEV), in_shift=shift.to(DEV), want_stats=True)
+    got = z.permute(0, 3, 1, 2).cpu()
+    assert torch.isfinite(got).all()
+    assert rel_err(got, ref) < 1e-4
+    e4 = rel_err(got.double(), ref64)
+    assert e4 < 1e-5, e4
+    s = stats.sum(dim=0).cpu()
+    assert torch.allclose(s[:, 0], ref.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(s[:, 1], (ref * ref).sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
+    # the three-pass form computes the same transforms around a differently ordered GEMM
+    z3, _ = ops.conv3x3_winograd4(x, w.to(DEV), b.to(DEV), in_scale=scale.to(DEV), in_shift=shift.to(DEV))
+    assert rel_err(z.cpu(), z3.cpu()) < 1e-5
+    # plain input (layer after a pool), no bias, no statistics
+    ref2 = F.conv2d(zprev, w, None, padding=1)
+    z2, st2 = ops.conv3x3_wino4f(x, w.to(DEV))
+    assert st2 is None and rel_err(z2.permute(0, 3, 1, 2).cpu(), ref2) < 1e-4
+    if H % 2 == 0 and W % 2 == 0:
+        zmax, zmin, st3 = ops.conv3x3_wino4f(x, w.to(DEV), b.to(DEV), in_scale=scale.to(DEV), in_shift=shift.to(DEV), want_stats=True, pool=True)
+        zw = z.view(N, H // 2, 2, W // 2, 2, cout)
+        assert torch.equal(zmax, zw.amax(dim=(2, 4))) and torch.equal(zmin, zw.amin(dim=(2, 4)))       # the same registers, stored differently
+        assert torch.allclose(st3.sum(dim=0).cpu(), s, rtol=1e-5, atol=1e-3)
+    print(f'wino4f {case}: max err / max |out| vs fp64 {e4:.2e}; three-pass {rel_err(z3.permute(0, 3, 1, 2).cpu().double(), ref64):.2e}')
+
+
 @pytest.mark.parametrize('case', [(2, 19, 19, 256, 150), (1, 16, 16, 512, 100), (3, 10, 13, 256, 64)])
 def test_dgrad_winograd4(case):
     """Data gradient of a detector-head-like 3x3/s1/p1 layer through the F(4x4) passes (adjoint convolution of the channel-padded dy) vs
