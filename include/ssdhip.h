@@ -84,6 +84,8 @@ typedef struct {
     float* ws;              /* NULL, or split-K workspace of ws_bytes bytes (ssdhip_conv2d_ws_bytes): launches whose tile grid cannot
                                fill the chip (tiny maps) split K over blocks and sum the partial tiles in a second, fixed-order pass */
     int64_t ws_bytes;
+    int32_t max_cus;        /* 0 = all; > 0: the persistent work-queue plane GEMM fills at most this many CUs (two blocks each) and leaves the
+                               rest to kernels of other streams (a full grid holds every register of every CU for the whole launch) */
 } ssdhip_conv_params;
 int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream);
 int64_t ssdhip_conv2d_ws_bytes(const ssdhip_conv_params* p);   /* split-K workspace this launch can use (0 = it does not split) */

@@ -26,7 +26,7 @@ class ConvParams(Structure):
                 ('Ho', c_int32), ('Wo', c_int32), ('Cout', c_int32),
                 ('R', c_int32), ('S', c_int32), ('stride', c_int32), ('pad', c_int32),
                 ('KP', c_int32), ('mode', c_int32), ('accumulate', c_int32), ('tile', c_int32),
-                ('rows_per_img', c_int32), ('w_img_stride', c_int64), ('compute', c_int32), ('ws', c_void_p), ('ws_bytes', c_int64)]
+                ('rows_per_img', c_int32), ('w_img_stride', c_int64), ('compute', c_int32), ('ws', c_void_p), ('ws_bytes', c_int64), ('max_cus', c_int32)]
 
 
 class WgradParams(Structure):

@@ -27,7 +27,7 @@
 // gemm_planes.hip: LDS-DMA staged plane GEMM (Winograd domain)
 long long ssdhip_gemm_planes_queue_ws_bytes(void);
 int ssdhip_gemm_planes_queue(const float* v, const float* u, float* y, int M, int K, int Cout, int rows_per_plane, long long u_plane_stride,
-                             void* ws, hipStream_t st);
+                             void* ws, int max_cus, hipStream_t st);
 int ssdhip_gemm_planes_dma(const float* v, const float* u, float* y, int M, int K, int Cout, int rows_per_plane, long long u_plane_stride,
                            int BM, int BN, int tpb, hipStream_t st, int abl);
 
@@ -667,7 +667,7 @@ int ssdhip_conv2d_nhwc(const ssdhip_conv_params* p, void* stream) {
         }
         if (probe == 0 && p->tile == 128128 && BM == 128 && BN == 128 && p->KP == p->Cin && p->Cin % BK == 0 && p->Cin >= 256 && p->ws &&
             p->ws_bytes >= ssdhip_gemm_planes_queue_ws_bytes() && plane_queue_wins(a.MB, a.NB, p->Cin)) {
-            int rc = ssdhip_gemm_planes_queue(p->x, p->w, p->y, a.M, p->Cin, p->Cout, p->rows_per_img, p->w_img_stride, p->ws, (hipStream_t)stream);
+            int rc = ssdhip_gemm_planes_queue(p->x, p->w, p->y, a.M, p->Cin, p->Cout, p->rows_per_img, p->w_img_stride, p->ws, p->max_cus, (hipStream_t)stream);
             if (rc != SSDHIP_OK) { ssdhip_set_error("conv2d: plane GEMM work-queue kernel not available on this device"); return rc; }
             SSDHIP_CHECK_LAUNCH();
             return SSDHIP_OK;

@@ -17,6 +17,7 @@
 //                                     4..32 K-steps), storing each finished tile from inside the loop
 //   tile order                        XCD-aware, n-tiles of an m-chunk adjacent (V rows are read once per n-tile from L2)
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -718,7 +719,7 @@ long long ssdhip_gemm_planes_queue_ws_bytes(void) {
 // 128 x 128 tiles, K >= 256: the persistent work-queue kernel.  ws: ssdhip_gemm_planes_queue_ws_bytes() bytes whose first 4 KiB were zero
 // before the first launch on it (launches on one workspace must be stream-ordered).
 int ssdhip_gemm_planes_queue(const float* v, const float* u, float* y, int M, int K, int Cout, int rows_per_plane, long long u_plane_stride,
-                             void* ws, hipStream_t st) {
+                             void* ws, int max_cus, hipStream_t st) {
     PlaneQArgs a;
     a.v = v; a.u = u; a.y = y; a.u_plane_stride = u_plane_stride;
     a.ctl = reinterpret_cast<int*>(ws);
@@ -726,6 +727,13 @@ int ssdhip_gemm_planes_queue(const float* v, const float* u, float* y, int M, in
     a.M = M; a.K = K; a.KT = K / BK; a.Cout = Cout; a.rows_per_plane = rows_per_plane;
     a.MB = M / 128; a.NB = cdiv(Cout, 128);
     a.S = ssdhip_cu_count() * 2 / 8;
+    // max_cus (ssdhip_conv_params; A/B override: SSD_PQ_CUS) = CUs the persistent grid fills, two blocks each: a full grid holds every
+    // register of every CU for the whole launch, so kernels of other streams only get in between launches.  Beside the trainable tail the
+    // engine asks for 208 of 256: 9.53 vs 9.57 ms per step (three alternating runs on one box; 216: 9.62, 224: 9.53-9.59, 192: 9.57).  The
+    // workspace is sized for the full grid either way.
+    static const int pq_env = [] { const char* e = getenv("SSD_PQ_CUS"); return e ? atoi(e) : -1; }();
+    const int pq_cus = pq_env >= 0 ? pq_env : max_cus;
+    if (pq_cus >= 8 && pq_cus * 2 / 8 < a.S) a.S = pq_cus * 2 / 8;
     if (a.S < 1 || a.S > 64) return SSDHIP_ENOSUP;      // piece counters: 64 per XCD
     hipLaunchKernelGGL(gemm_planes_queue_kernel, dim3(8 * a.S), dim3(512), 0, st, a);
     return SSDHIP_OK;

@@ -134,6 +134,7 @@ class Engine:
         self._cus = None       # compute units of the device (first forward): the persistent backbone grids take 7/8 of them beside the tail
         self._wf_blocks_env = os.environ.get('SSD_WF_BLOCKS')
         self._wf_blocks = int(self._wf_blocks_env) if self._wf_blocks_env is not None else 0
+        self._pq_cus = 0
         self._fused_min = int(os.environ.get('SSD_FUSED_MIN', '70'))      # smallest map side that runs on the fused Winograd kernel
         # phased execution (graph_step.py): the frozen backbone and the trainable tail as two separately enqueued (captured) pieces.
         # What the tail reads of the backbone -- z and BN state of the stages with a detector head and of the last frozen stage --
@@ -343,6 +344,7 @@ class Engine:
                 ws = torch.zeros((need + 3) // 4, device=torch.device('cuda', torch.cuda.current_device()), dtype=torch.float32)
                 bufs[key] = ws
             p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
+            p.max_cus = self._pq_cus
         for gi in range(groups):
             p.x = x0 + gi * per * tp * cin * 4
             p.w = w0 + gi * per * w_plane_stride * 4
@@ -350,7 +352,7 @@ class Engine:
             _lib.check(self.lib.ssdhip_conv2d_nhwc(ctypes.byref(p), _lib.stream()), what)
         queued = bool(p.ws)
         p.x, p.w, p.y, p.N = x0, w0, y0, planes
-        p.ws, p.ws_bytes, p.compute = None, 0, 0
+        p.ws, p.ws_bytes, p.compute, p.max_cus = None, 0, 0, 0
         return queued
 
     def _wino4_ok(self, c, g, sizing=False):
@@ -649,6 +651,8 @@ class Engine:
             # 7/8 of the CUs (224 of 256 on an MI355X), a multiple of 32 so that every XCD gets whole channel-tile groups
             beside_tail = (bb is not None or (phase != 'all' and not self.single_stream)) and self.tail_start < len(self.stages)
             self._wf_blocks = max(32, self._cus * 7 // 8 // 32 * 32) if beside_tail else 0
+            # the persistent work-queue plane GEMM: 13/16 of the CUs (208 of 256) beside the tail (gemm_planes.hip: 9.53 vs 9.57 ms per step)
+            self._pq_cus = max(8, self._cus * 13 // 16 // 8 * 8) if beside_tail else 0
         entry = main.record_event() if fork.side_stream is not None else None
         if fork.side_stream is not None:
             fork.side_stream.wait_event(entry)               # `out` may reuse memory that step i's loss kernels still read

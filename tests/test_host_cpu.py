@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header(tmp_path):
     """The ctypes mirrors must have the C layout include/ssdhip.h declares: ask the C compiler for size and field offsets."""
     import subprocess
-    fields = {'ssdhip_conv_params': (_lib.ConvParams, ['x', 'y_batch_stride', 'N', 'KP', 'tile', 'rows_per_img', 'w_img_stride', 'compute']),
+    fields = {'ssdhip_conv_params': (_lib.ConvParams, ['x', 'y_batch_stride', 'N', 'KP', 'tile', 'rows_per_img', 'w_img_stride', 'compute', 'ws_bytes', 'max_cus']),
               'ssdhip_wgrad_params': (_lib.WgradParams, ['x', 'ws', 'dy_batch_stride', 'N', 'pad', 'dy_row', 'dw_cin', 'wino_v'])}
     prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT}/include/ssdhip.h"', 'int main(void) {']
     for t, (_, names) in fields.items():
