@@ -371,6 +371,12 @@ def main():
             roof['cus_used'] = eng._wf_blocks
             roof['frac_of_cus_used'] = round(roof['frac'] * 256.0 / eng._wf_blocks, 4)
             notes.append(f'the kernel is launched on {eng._wf_blocks} of the 256 CUs (the rest is left to the concurrent tail streams)')
+        if name.startswith('gemm_planes_queue_kernel') and getattr(eng, '_pq_cus', 0):
+            # opt-in SSD_PQ_CUS: the persistent work-queue GEMM on fewer CUs beside the tail's streams; `frac` stays priced against the
+            # whole chip's peak, this field prices the same launches against the CUs they occupy
+            roof['cus_used'] = eng._pq_cus
+            roof['frac_of_cus_used'] = round(roof['frac'] * float(eng._cus) / eng._pq_cus, 4)
+            notes.append(f'SSD_PQ_CUS: the kernel is launched on {eng._pq_cus} of the {eng._cus} CUs (the rest is left to the concurrent tail streams)')
         roof['note'] = '; '.join(notes) if notes else None
     eng.prof = None
 

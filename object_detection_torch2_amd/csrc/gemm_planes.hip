@@ -727,13 +727,11 @@ int ssdhip_gemm_planes_queue(const float* v, const float* u, float* y, int M, in
     a.M = M; a.K = K; a.KT = K / BK; a.Cout = Cout; a.rows_per_plane = rows_per_plane;
     a.MB = M / 128; a.NB = cdiv(Cout, 128);
     a.S = ssdhip_cu_count() * 2 / 8;
-    // max_cus (ssdhip_conv_params; A/B override: SSD_PQ_CUS) = CUs the persistent grid fills, two blocks each: a full grid holds every
-    // register of every CU for the whole launch, so kernels of other streams only get in between launches.  Beside the trainable tail the
-    // engine asks for 208 of 256: 9.53 vs 9.57 ms per step (three alternating runs on one box; 216: 9.62, 224: 9.53-9.59, 192: 9.57).  The
-    // workspace is sized for the full grid either way.
-    static const int pq_env = [] { const char* e = getenv("SSD_PQ_CUS"); return e ? atoi(e) : -1; }();
-    const int pq_cus = pq_env >= 0 ? pq_env : max_cus;
-    if (pq_cus >= 8 && pq_cus * 2 / 8 < a.S) a.S = pq_cus * 2 / 8;
+    // max_cus (ssdhip_conv_params) = CUs the persistent grid fills, two blocks each: a full grid holds every register of every CU for the
+    // whole launch, so kernels of other streams only get in between launches.  Measured beside the trainable tail (engine: SSD_PQ_CUS): 208 of
+    // 256 CUs 9.53 vs 9.57 ms per step over three alternating runs on one box (216: 9.62, 224: 9.53-9.59, 192: 9.57).  The workspace is sized
+    // for the full grid either way.
+    if (max_cus >= 8 && max_cus * 2 / 8 < a.S) a.S = max_cus * 2 / 8;
     if (a.S < 1 || a.S > 64) return SSDHIP_ENOSUP;      // piece counters: 64 per XCD
     hipLaunchKernelGGL(gemm_planes_queue_kernel, dim3(8 * a.S), dim3(512), 0, st, a);
     return SSDHIP_OK;

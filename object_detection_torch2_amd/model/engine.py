@@ -134,7 +134,9 @@ class Engine:
         self._cus = None       # compute units of the device (first forward): the persistent backbone grids take 7/8 of them beside the tail
         self._wf_blocks_env = os.environ.get('SSD_WF_BLOCKS')
         self._wf_blocks = int(self._wf_blocks_env) if self._wf_blocks_env is not None else 0
-        self._pq_cus = 0
+        # opt-in (SSD_PQ_CUS=208): CUs the persistent work-queue plane GEMM fills (ssdhip_conv_params.max_cus); 208 of 256 beside the tail: 9.53 vs 9.57 ms per
+        # step -- not the default: the launch the bench line's `roofline` prices would then run on 13/16 of the chip by design
+        self._pq_cus = int(os.environ.get('SSD_PQ_CUS', '0'))
         self._fused_min = int(os.environ.get('SSD_FUSED_MIN', '70'))      # smallest map side that runs on the fused Winograd kernel
         # phased execution (graph_step.py): the frozen backbone and the trainable tail as two separately enqueued (captured) pieces.
         # What the tail reads of the backbone -- z and BN state of the stages with a detector head and of the last frozen stage --
@@ -651,8 +653,6 @@ class Engine:
             # 7/8 of the CUs (224 of 256 on an MI355X), a multiple of 32 so that every XCD gets whole channel-tile groups
             beside_tail = (bb is not None or (phase != 'all' and not self.single_stream)) and self.tail_start < len(self.stages)
             self._wf_blocks = max(32, self._cus * 7 // 8 // 32 * 32) if beside_tail else 0
-            # the persistent work-queue plane GEMM: 13/16 of the CUs (208 of 256) beside the tail (gemm_planes.hip: 9.53 vs 9.57 ms per step)
-            self._pq_cus = max(8, self._cus * 13 // 16 // 8 * 8) if beside_tail else 0
         entry = main.record_event() if fork.side_stream is not None else None
         if fork.side_stream is not None:
             fork.side_stream.wait_event(entry)               # `out` may reuse memory that step i's loss kernels still read
