@@ -575,7 +575,8 @@ class Engine:
         if st is None:
             # the frozen backbone (which = 2) fills the chip with long launches; the side stream's short, dependent launches (heads,
             # weight gradients, repacking) go first whenever both have work ready (SSD_STREAM_PRIO=0 disables)
-            prio = -1 if (which != 2 and os.environ.get('SSD_STREAM_PRIO', '1') == '1') else 0
+            mode = os.environ.get('SSD_STREAM_PRIO', '1')       # 1 (default): side streams high; 0: all normal; bb (A/B): the backbone stream high instead
+            prio = -1 if ((which != 2 and mode == '1') or (which == 2 and mode == 'bb')) else 0
             st = torch.cuda.Stream(device=dev, priority=prio)
             self._side[(dev, which)] = st
         return st
