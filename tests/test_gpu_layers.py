@@ -556,6 +556,18 @@ def test_plane_gemm_work_queue_matches_slot_kernel():
             torch.cuda.synchronize()
             assert torch.equal(M1, first), shift
             assert bool((ws[:1024].view(torch.int32) == 0).all()), shift
+        # a smaller persistent grid (ssdhip_conv_params.max_cus: CUs left to other streams) changes which tiles the last round splits, not
+        # what a tile is: everything written, whole tiles bit-equal to the slot kernel, control words back at zero
+        for cus in (208, 64):
+            M1.fill_(float('nan'))
+            p.max_cus = cus
+            _lib.check(lib.ssdhip_conv2d_nhwc(ctypes.byref(p), st), 'queue kernel on fewer CUs')
+            torch.cuda.synchronize()
+            p.max_cus = 0
+            assert torch.isfinite(M1).all()
+            differ = int((M0.view(-1, 128, cout) != M1.view(-1, 128, cout)).any(dim=1).view(-1, cout // 128, 128).any(dim=2).sum())
+            assert differ <= 8 * 31 and (M0 - M1).abs().max().item() <= 4e-6 * M0.abs().max().item(), (cus, differ)
+            assert bool((ws[:1024].view(torch.int32) == 0).all()), cus
 
 
 def test_plane_gemm_split_bf16_is_as_exact_as_the_fp32_mfma():
