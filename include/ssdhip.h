@@ -310,6 +310,13 @@ int ssdhip_wino_fused_conv(const float* x, const float* upk, const float* bias, 
 int ssdhip_wino_fused_conv_pool(const float* x, const float* upk, const float* bias, const float* in_scale, const float* in_shift,
                                 float* zmax, float* zmin, float* stats, const void* geo, int N, int H, int W, int Cin, int Cout,
                                 int max_blocks, void* stream);
+/* the same, storing per pooling window only the extreme the pool will use: the maximum where bn_weight[co] >= 0, else the minimum (the sign
+ * of a channel's BatchNorm scale gamma * invstd is gamma's, known before the batch statistics).  zsel (N, H/2, W/2, Cout); consumer:
+ * ssdhip_bn_relu_pool(zsel, scale, shift, y, ..., pool = 0) -- bit-identical to conv -> ssdhip_bn_relu_pool(pool = 1), half the stores of the
+ * pair form and a third less for the consumer to read */
+int ssdhip_wino_fused_conv_pool_sel(const float* x, const float* upk, const float* bias, const float* in_scale, const float* in_shift,
+                                    const float* bn_weight, float* zsel, float* stats, const void* geo, int N, int H, int W, int Cin, int Cout,
+                                    int max_blocks, void* stream);
 int ssdhip_bn_relu_select(const float* zmax, const float* zmin, const float* scale, const float* shift, float* y, int64_t pixels, int C,
                           void* stream);
 

@@ -107,6 +107,8 @@ SIGNATURES = {
                                        c_int, c_int, c_int, c_void_p]),
     'ssdhip_wino_fused_conv_pool': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                             c_int, c_int, c_int, c_void_p]),
+    'ssdhip_wino_fused_conv_pool_sel': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                        c_int, c_int, c_int, c_void_p]),
     'ssdhip_bn_relu_select': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     'ssdhip_conv_bf16_weight_bytes': (c_int64, [c_int, c_int]),
     'ssdhip_conv_bf16_pack': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),

@@ -82,6 +82,7 @@ struct WfArgs {
     float* stats;
     float* zmax;      // 2x2 max-pool fusion (8-wave kernel): per tile = pooling window the maximum and the minimum of z instead of z itself
     float* zmin;
+    const float* gsel;  // POOL = 2: BatchNorm weight of the layer's own BatchNorm; the sign of gamma[co] is the sign of its scale = which extreme the pool needs
     int H, W, C, Cout, KT, NB, MB;
     unsigned x_bytes;
     int band;         // 1 = an XCD walks a contiguous band of tile blocks (see the kernel), 0 = tile blocks dealt round-robin over the XCDs
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifndef WF8_MIDP
 #define WF8_MIDP 1      // plane slot of the mid-step barrier + raw-tile refill (A/B: -DWF8_MIDP=2 / 3)
 #endif
-template <bool XFORM, int ABL = 0, bool POOL = false>       // ABL: timing-only ablations (probe builds; wrong results): 1 no raw-tile DMA, 2 no weight DMA, 4 no transform, 8 no stores; POOL: store window max / min instead of z
+template <bool XFORM, int ABL = 0, int POOL = 0>       // ABL: timing-only ablations (probe builds; wrong results): 1 no raw-tile DMA, 2 no weight DMA, 4 no transform, 8 no stores; POOL: 1 = store window max / min instead of z, 2 = only the one of them the pool will use
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_fused8_kernel(WfArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -671,6 +672,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned b_rd = lds0 + (unsigned)(WF_B_OFF + wn * 1024 + li * 64 + ((kq ^ ((4 - (li >> 2)) & 3)) * 16));
     const int co0 = n0 + 32 * wn + 2 * li;                 // this lane's two output channels: co0 (column group 0), co0 + 1 (group 1)
     const float bv0 = a.bias ? a.bias[co0] : 0.f, bv1 = a.bias ? a.bias[co0 + 1] : 0.f;
+    // POOL = 2: relu(bn(.)) rises with z where the BatchNorm scale gamma * invstd is >= 0 and falls below: the sign is gamma's, known before the batch statistics
+    const bool up0 = POOL == 2 ? a.gsel[co0] >= 0.f : true, up1 = POOL == 2 ? a.gsel[co0 + 1] >= 0.f : true;
     const int WC = a.W * a.Cout;
 
 #pragma clang loop unroll(disable)
@@ -767,7 +770,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 // is never written: a quarter of the store traffic twice instead of once in full, and the pool pass reads 2/4 instead of 4/4.
                 if ((ent.x >> 8) & 1) {
                     float* pm = a.zmax + ((size_t)mb * WF_TILES + i) * a.Cout + co0;
-                    float* pn = a.zmin + ((size_t)mb * WF_TILES + i) * a.Cout + co0;
+                    float* pn = POOL == 2 ? nullptr : a.zmin + ((size_t)mb * WF_TILES + i) * a.Cout + co0;
                     float mx[2], mn[2];
 #pragma unroll
                     for (int cg = 0; cg < 2; ++cg) {
@@ -779,8 +782,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                             for (int bb = 0; bb < 2; ++bb) { s1[cg] += y[cg][aa][bb]; s2[cg] += y[cg][aa][bb] * y[cg][aa][bb]; }
                     }
                     if (!(ABL & 8)) {
-                        *reinterpret_cast<float2*>(pm) = make_float2(mx[0], mx[1]);
-                        *reinterpret_cast<float2*>(pn) = make_float2(mn[0], mn[1]);
+                        if (POOL == 2) {
+                            *reinterpret_cast<float2*>(pm) = make_float2(up0 ? mx[0] : mn[0], up1 ? mx[1] : mn[1]);
+                        } else {
+                            *reinterpret_cast<float2*>(pm) = make_float2(mx[0], mx[1]);
+                            *reinterpret_cast<float2*>(pn) = make_float2(mn[0], mn[1]);
+                        }
                     }
                 }
                 continue;
@@ -877,9 +884,9 @@ int ssdhip_wino_fused_geo(int N, int H, int W, void* geo, void* stream) {
 }
 
 static int wino_fused_launch(const float* x, const float* upk, const float* bias, const float* in_scale, const float* in_shift, float* z,
-                             float* zmax, float* zmin, float* stats, const void* geo, int N, int H, int W, int Cin, int Cout, int max_blocks,
-                             void* stream) {
-    SSDHIP_REQUIRE(x && upk && (z || (zmax && zmin)) && geo && N > 0 && H > 0 && W > 0 && max_blocks >= 0, "wino_fused_conv: bad arguments");
+                             float* zmax, float* zmin, const float* gsel, float* stats, const void* geo, int N, int H, int W, int Cin, int Cout,
+                             int max_blocks, void* stream) {
+    SSDHIP_REQUIRE(x && upk && (z || (zmax && (zmin || gsel))) && geo && N > 0 && H > 0 && W > 0 && max_blocks >= 0, "wino_fused_conv: bad arguments");
     SSDHIP_REQUIRE(Cin >= 32 && Cin % 16 == 0 && Cin <= WF_MAXC && Cout > 0 && Cout % WF_COUT == 0,
                    "wino_fused_conv: Cin must be a multiple of 16 in 32..512 and Cout a multiple of 64");
     SSDHIP_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "wino_fused_conv: in_scale and in_shift go together");
@@ -894,8 +901,10 @@ static int wino_fused_launch(const float* x, const float* upk, const float* bias
     if (const int dev = attr.pending(); dev != DeviceOnce::kDone) {
         bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) == hipSuccess &&
                   hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) == hipSuccess &&
-                  hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused8_kernel<true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) == hipSuccess &&
-                  hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused8_kernel<false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) == hipSuccess;
+                  hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused8_kernel<true, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) == hipSuccess &&
+                  hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused8_kernel<false, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) == hipSuccess &&
+                  hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused8_kernel<true, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) == hipSuccess &&
+                  hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused8_kernel<false, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) == hipSuccess;
 #ifdef SSDHIP_PROBES
         ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) == hipSuccess &&
              hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS) == hipSuccess;
@@ -907,7 +916,7 @@ static int wino_fused_launch(const float* x, const float* upk, const float* bias
         attr.mark(dev);
     }
     WfArgs a;
-    a.x = x; a.upk = upk; a.bias = bias; a.scale = in_scale; a.shift = in_shift; a.z = z; a.stats = stats; a.zmax = zmax; a.zmin = zmin;
+    a.x = x; a.upk = upk; a.bias = bias; a.scale = in_scale; a.shift = in_shift; a.z = z; a.stats = stats; a.zmax = zmax; a.zmin = zmin; a.gsel = gsel;
     a.geo = reinterpret_cast<const int*>(geo);
     a.H = H; a.W = W; a.C = Cin; a.Cout = Cout;
     a.KT = Cin / WF_BK; a.NB = Cout / WF_COUT;
@@ -955,9 +964,12 @@ static int wino_fused_launch(const float* x, const float* upk, const float* bias
         return a.MB;
     }
 #endif
-    if (zmax != nullptr) {
-        if (in_scale) hipLaunchKernelGGL((wino_fused8_kernel<true, 0, true>), grid, dim3(512), WF_LDS, st, a);
-        else hipLaunchKernelGGL((wino_fused8_kernel<false, 0, true>), grid, dim3(512), WF_LDS, st, a);
+    if (zmax != nullptr && gsel != nullptr) {
+        if (in_scale) hipLaunchKernelGGL((wino_fused8_kernel<true, 0, 2>), grid, dim3(512), WF_LDS, st, a);
+        else hipLaunchKernelGGL((wino_fused8_kernel<false, 0, 2>), grid, dim3(512), WF_LDS, st, a);
+    } else if (zmax != nullptr) {
+        if (in_scale) hipLaunchKernelGGL((wino_fused8_kernel<true, 0, 1>), grid, dim3(512), WF_LDS, st, a);
+        else hipLaunchKernelGGL((wino_fused8_kernel<false, 0, 1>), grid, dim3(512), WF_LDS, st, a);
     } else if (in_scale) hipLaunchKernelGGL(wino_fused8_kernel<true>, grid, dim3(512), WF_LDS, st, a);
     else hipLaunchKernelGGL(wino_fused8_kernel<false>, grid, dim3(512), WF_LDS, st, a);
     SSDHIP_CHECK_LAUNCH();
@@ -967,14 +979,21 @@ static int wino_fused_launch(const float* x, const float* upk, const float* bias
 int ssdhip_wino_fused_conv(const float* x, const float* upk, const float* bias, const float* in_scale, const float* in_shift, float* z,
                            float* stats, const void* geo, int N, int H, int W, int Cin, int Cout, int max_blocks, void* stream) {
     SSDHIP_REQUIRE(z, "wino_fused_conv: bad arguments");
-    return wino_fused_launch(x, upk, bias, in_scale, in_shift, z, nullptr, nullptr, stats, geo, N, H, W, Cin, Cout, max_blocks, stream);
+    return wino_fused_launch(x, upk, bias, in_scale, in_shift, z, nullptr, nullptr, nullptr, stats, geo, N, H, W, Cin, Cout, max_blocks, stream);
 }
 
 int ssdhip_wino_fused_conv_pool(const float* x, const float* upk, const float* bias, const float* in_scale, const float* in_shift,
                                 float* zmax, float* zmin, float* stats, const void* geo, int N, int H, int W, int Cin, int Cout,
                                 int max_blocks, void* stream) {
     SSDHIP_REQUIRE(zmax && zmin && H % 2 == 0 && W % 2 == 0, "wino_fused_conv_pool: even H and W (a Winograd tile must be a pooling window)");
-    return wino_fused_launch(x, upk, bias, in_scale, in_shift, nullptr, zmax, zmin, stats, geo, N, H, W, Cin, Cout, max_blocks, stream);
+    return wino_fused_launch(x, upk, bias, in_scale, in_shift, nullptr, zmax, zmin, nullptr, stats, geo, N, H, W, Cin, Cout, max_blocks, stream);
+}
+
+int ssdhip_wino_fused_conv_pool_sel(const float* x, const float* upk, const float* bias, const float* in_scale, const float* in_shift,
+                                    const float* bn_weight, float* zsel, float* stats, const void* geo, int N, int H, int W, int Cin, int Cout,
+                                    int max_blocks, void* stream) {
+    SSDHIP_REQUIRE(zsel && bn_weight && H % 2 == 0 && W % 2 == 0, "wino_fused_conv_pool_sel: even H and W (a Winograd tile must be a pooling window)");
+    return wino_fused_launch(x, upk, bias, in_scale, in_shift, nullptr, zsel, nullptr, bn_weight, stats, geo, N, H, W, Cin, Cout, max_blocks, stream);
 }
 
 }  // extern "C"

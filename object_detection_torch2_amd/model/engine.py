@@ -128,6 +128,7 @@ class Engine:
         if self._wino_mode not in ('f2', 'f4'):
             raise ValueError(f"SSD_WINOGRAD must be 'f2' or 'f4', got {self._wino_mode!r}")
         self._pool_fuse = os.environ.get('SSD_NO_POOL_FUSE') != '1'      # A/B: conv + 2x2 max-pool without materialising z (conv_1_2, conv_2_2)
+        self._pool_pair = os.environ.get('SSD_POOL_PAIR') == '1'         # A/B: the pooled epilogue stores window maxima AND minima (round-3 form) instead of the one the pool uses
         self._w4_max_map = int(os.environ.get('SSD_W4_MAX_MAP', '160'))     # largest map side on the F(4x4) passes (SSD512: conv_3_2 / conv_3_3 at 128 px)
         self._early_f4 = os.environ.get('SSD_EARLY_F4', '0') == '1'       # opt-in: conv_2_2 / conv_3_1 on the two-pass F(4x4) form (csrc/wino4_fused.hip)
         self._w4_min_cin = int(os.environ.get('SSD_W4_MIN_CIN', '256'))      # A/B: 128 also routes conv_3_1 (K = 128) to the F(4x4) passes
@@ -771,7 +772,9 @@ class Engine:
                     if pool_fused:
                         zmm = b.setdefault('zmm', {}).get(i)
                         if zmm is None:
-                            zmm = torch.empty(2, N, g['ha'], g['wa'], c.cout, device=dev, dtype=torch.float32)
+                            # the window maxima and minima, or (default) only the extreme the pool will use: the sign of a channel's BatchNorm
+                            # scale is the sign of its weight, known before the batch statistics (SSD_POOL_PAIR=1: the pair form, for A/B)
+                            zmm = torch.empty(2 if (self._pool_pair or early_f4) else 1, N, g['ha'], g['wa'], c.cout, device=dev, dtype=torch.float32)
                             b['zmm'][i] = zmm
                     if early_f4:
                         if getattr(c, 'w4f_img', None) is None or c.w4f_img.device != w1.device or c.w4f_key != key:
@@ -792,6 +795,13 @@ class Engine:
                             rows = _lib.check(self.lib.ssdhip_wino4f_gemm(_lib.ptr(vb), _lib.ptr(c.w4f_img), _lib.ptr(b1) if b1 is not None else None,
                                                                           _lib.ptr(z), _lib.ptr(ws['partial']) if training else None,
                                                                           N, g['hi'], g['wi'], c.cin, c.cout, st), f'conv2d {c.name}')
+                    elif pool_fused and zmm.shape[0] == 1:
+                        rows = _lib.check(self.lib.ssdhip_wino_fused_conv_pool_sel(_lib.ptr(cur), _lib.ptr(c.wf_img), _lib.ptr(b1) if b1 is not None else None,
+                                                                                   _lib.ptr(cur_xs[0]) if cur_xs is not None else None,
+                                                                                   _lib.ptr(cur_xs[1]) if cur_xs is not None else None,
+                                                                                   _lib.ptr(bnm.weight), _lib.ptr(zmm[0]), _lib.ptr(ws['partial']) if training else None,
+                                                                                   _lib.ptr(self._wf_geo(b, N, g['hi'], g['wi'], dev)), N, g['hi'], g['wi'],
+                                                                                   c.cin, c.cout, self._wf_blocks, st), f'conv2d {c.name}')
                     elif pool_fused:
                         rows = _lib.check(self.lib.ssdhip_wino_fused_conv_pool(_lib.ptr(cur), _lib.ptr(c.wf_img), _lib.ptr(b1) if b1 is not None else None,
                                                                                _lib.ptr(cur_xs[0]) if cur_xs is not None else None,
@@ -815,7 +825,7 @@ class Engine:
                         e1.record()
                         tiles = N * ((g['hi'] + 1) // 2) * ((g['wi'] + 1) // 2)
                         self.prof.append(dict(layer=c.name + ' (fused Winograd)', e0=e0, e1=e1,
-                                              kernel='wino_fused8_kernel<%s, 0, %s>' % ('true' if cur_xs is not None else 'false', 'true' if pool_fused else 'false'),
+                                              kernel='wino_fused8_kernel<%s, 0, %d>' % ('true' if cur_xs is not None else 'false', (2 if zmm.shape[0] == 1 else 1) if pool_fused else 0),
                                               flops=2.0 * 16 * tiles * c.cin * c.cout,            # MFMA flops of the 16 Winograd-domain products
                                               direct_flops=2.0 * N * g['hi'] * g['wi'] * c.cin * c.cout * 9))
                 elif c.wino and self._wino_ok(g) and not self.bf16:     # bf16 MFMA outruns the fp32 Winograd pipeline: direct kernel
@@ -885,8 +895,12 @@ class Engine:
                 elif pool_fused:
                     pooled = b['pooled'][i] if not alt else self._alt(b, 'pooled', i, b['pooled'][i])
                     zmm = b['zmm'][i]
-                    _lib.check(self.lib.ssdhip_bn_relu_select(_lib.ptr(zmm[0]), _lib.ptr(zmm[1]), _lib.ptr(bst['scale']), _lib.ptr(bst['shift']),
-                                                              _lib.ptr(pooled), N * g['ha'] * g['wa'], c.cout, st), f'pool (select) after {c.name}')
+                    if zmm.shape[0] == 1:       # the producer stored the extreme the pool uses: BatchNorm.ReLU of it IS the pooled activation
+                        _lib.check(self.lib.ssdhip_bn_relu_pool(_lib.ptr(zmm[0]), _lib.ptr(bst['scale']), _lib.ptr(bst['shift']), _lib.ptr(pooled),
+                                                                N, g['ha'], g['wa'], c.cout, 0, 0, st), f'pool (selected extreme) after {c.name}')
+                    else:
+                        _lib.check(self.lib.ssdhip_bn_relu_select(_lib.ptr(zmm[0]), _lib.ptr(zmm[1]), _lib.ptr(bst['scale']), _lib.ptr(bst['shift']),
+                                                                  _lib.ptr(pooled), N * g['ha'] * g['wa'], c.cout, st), f'pool (select) after {c.name}')
                     cur, cur_xs = pooled, None
                 elif s.pool_pad is not None:
                     pooled = b['pooled'][i] if not alt else self._alt(b, 'pooled', i, b['pooled'][i])

@@ -177,6 +177,28 @@ def wino_fused_conv_pool(x, w_oihw, bias=None, in_scale=None, in_shift=None, wan
     return zmax, zmin, stats
 
 
+def wino_fused_conv_pool_sel(x, w_oihw, bn_weight, bias=None, in_scale=None, in_shift=None, want_stats=False, upk=None, max_blocks=0):
+    """As wino_fused_conv_pool, but only the extreme the pool will use is stored: per window the maximum of z where bn_weight[co] >= 0, else
+    the minimum.  Returns (zsel (N,H/2,W/2,Cout), stats or None); bn_relu_pool(zsel, scale, shift, pool=False) is then the pooled activation."""
+    _lib.require_gpu(x, w_oihw, bn_weight)
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    cout, cin = w_oihw.shape[0], w_oihw.shape[1]
+    if cin != C or H % 2 or W % 2 or bn_weight.numel() != cout:
+        raise ValueError('wino_fused_conv_pool_sel: channel mismatch or odd map size')
+    if upk is None:
+        upk = wino_fused_pack(w_oihw)
+    zsel = torch.empty(N, H // 2, W // 2, cout, device=x.device, dtype=torch.float32)
+    stats = torch.empty(_lib.check(lib.ssdhip_wino_fused_stat_rows(N, H, W), 'wino_fused_stat_rows'), cout, 2, device=x.device,
+                        dtype=torch.float32) if want_stats else None
+    _lib.check(lib.ssdhip_wino_fused_conv_pool_sel(_lib.ptr(x), _lib.ptr(upk), _lib.ptr(bias) if bias is not None else None,
+                                                   _lib.ptr(in_scale) if in_scale is not None else None,
+                                                   _lib.ptr(in_shift) if in_shift is not None else None, _lib.ptr(_lib.f32c(bn_weight)), _lib.ptr(zsel),
+                                                   _lib.ptr(stats) if stats is not None else None, _lib.ptr(wino_fused_geo(N, H, W, x.device)),
+                                                   N, H, W, C, cout, max_blocks, _lib.stream()), 'wino_fused_conv_pool_sel')
+    return zsel, stats
+
+
 def bn_relu_select(zmax, zmin, scale, shift):
     """max-pool(relu(bn(z))) from the window maxima / minima of z (see wino_fused_conv_pool)."""
     _lib.require_gpu(zmax, zmin, scale, shift)

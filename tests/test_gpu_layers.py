@@ -442,6 +442,24 @@ def test_conv3x3_winograd_fused_with_pool(case):
     ref = F.max_pool2d(F.relu(F.conv2d(F.relu(zprev * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)), w, b, padding=1) * sc2.view(1, -1, 1, 1)
                               + sh2.view(1, -1, 1, 1)), 2)
     assert rel_err(got.permute(0, 3, 1, 2).cpu(), ref) < 1e-4
+    # the form the engine launches: only the extreme the pool will use is stored -- the sign of a BatchNorm scale gamma * invstd is gamma's.
+    # Weights of both signs, zero and -0.0 (scale = gamma * invstd with invstd > 0 keeps every one of those signs)
+    gamma = rnd(cout, seed=338)
+    gamma[::7] = 0.0
+    gamma[3::11] = -0.0
+    invstd = torch.rand(cout, generator=torch.Generator().manual_seed(339)) + 0.5
+    sc3 = gamma * invstd
+    zsel, st3 = ops.wino_fused_conv_pool_sel(x, w.to(DEV), gamma.to(DEV), b.to(DEV), in_scale=scale.to(DEV), in_shift=shift.to(DEV), want_stats=True)
+    assert torch.equal(st, st3)
+    assert torch.equal(zsel, torch.where((gamma >= 0).to(DEV), zmax, zmin))
+    want3 = ops.bn_relu_pool(z, sc3.to(DEV), sh2.to(DEV), pool=True, pool_pad=0)
+    got3 = ops.bn_relu_pool(zsel, sc3.to(DEV), sh2.to(DEV), pool=False)
+    assert torch.equal(got3, want3)
+    # plain input (no BatchNorm.ReLU on load), no bias, no statistics
+    zsel2, st4 = ops.wino_fused_conv_pool_sel(x, w.to(DEV), gamma.to(DEV))
+    z2, _ = ops.wino_fused_conv(x, w.to(DEV))
+    zz2 = z2.view(N, H // 2, 2, W // 2, 2, cout)
+    assert st4 is None and torch.equal(zsel2, torch.where((gamma >= 0).to(DEV), zz2.amax(dim=(2, 4)), zz2.amin(dim=(2, 4))))
 
 
 # (N, H, W, Cin, Cout): conv_6_1-like and detector-head-like (Cout padded 150 -> 160, 100 -> 128), odd / even maps
