@@ -53,6 +53,15 @@ int ssdhip_normalize_nchw_to_nhwc4(const float* x, float* y, int N, int H, int W
  * (model/ssd.py:61,70-77 nn.Conv2d weights; repacked after each optimizer step for trainable layers)     */
 int ssdhip_pack_conv_weight(const float* w_oihw, float* packed, int Cout, int Cin, int R, int S,
                             int rows_pad, int inner_pad, int KP, int mode, void* stream);
+/* the same for many tensors in one launch (an optimizer step changes every trainable weight: ~26 layouts): `jobs_device` = n_jobs records in
+ * DEVICE memory, each the argument list of one ssdhip_pack_conv_weight call (validated by the caller); max_elements = the largest
+ * rows_pad * KP among them */
+typedef struct {
+    const float* w;
+    float* packed;
+    int32_t Cout, Cin, R, S, rows_pad, inner_pad, KP, mode;
+} ssdhip_pack_job;
+int ssdhip_pack_conv_weights(const ssdhip_pack_job* jobs_device, int n_jobs, int64_t max_elements, void* stream);
 
 /* ---- A3/A7  nn.Conv2d forward as NHWC implicit GEMM on v_mfma_f32_32x32x2_f32 ---------------------------
  * (model/vgg16.py:33, model/ssd.py:61,70-77,103-104).  Also used for dgrad (mode 1) with mode-1 packed weights.

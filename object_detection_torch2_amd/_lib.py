@@ -45,6 +45,7 @@ SIGNATURES = {
     'ssdhip_default_boxes': (c_int, [c_void_p, POINTER(c_int32), c_int, c_double, c_double, c_void_p]),
     'ssdhip_normalize_nchw_to_nhwc4': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'ssdhip_pack_conv_weight': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'ssdhip_pack_conv_weights': (c_int, [c_void_p, c_int, c_int64, c_void_p]),
     'ssdhip_conv2d_nhwc': (c_int, [POINTER(ConvParams), c_void_p]),
     'ssdhip_conv2d_block_m': (c_int, [POINTER(ConvParams)]),
     'ssdhip_conv2d_ws_bytes': (c_int64, [POINTER(ConvParams)]),

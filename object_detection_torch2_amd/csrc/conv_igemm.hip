@@ -499,8 +499,8 @@ static int plan_split(int MB, int NB, int KT, int64_t M, int Cout, int64_t ws_by
 }
 
 // OIHW -> packed rows.  mode 0: row = co, inner = ci;  mode 1: row = ci, inner = co.  k order as the loader walks it.
-__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cout, int Cin, int R, int S,
-                                   int rows_pad, int inner_pad, int KP, int mode) {
+__device__ __forceinline__ void pack_weight_body(const float* __restrict__ w, float* __restrict__ packed, int Cout, int Cin, int R, int S,
+                                                 int rows_pad, int inner_pad, int KP, int mode) {
     const int64_t total = (int64_t)rows_pad * KP;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int row = (int)(i / KP), k = (int)(i - (int64_t)row * KP);
@@ -519,6 +519,17 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
         }
         packed[i] = v;
     }
+}
+
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cout, int Cin, int R, int S,
+                                   int rows_pad, int inner_pad, int KP, int mode) {
+    pack_weight_body(w, packed, Cout, Cin, R, S, rows_pad, inner_pad, KP, mode);
+}
+
+// every layout of one optimizer step in ONE launch: blockIdx.y = job (the trainable tail repacks ~26 weight tensors per step, 5 us each)
+__global__ void pack_weights_batched_kernel(const ssdhip_pack_job* __restrict__ jobs) {
+    const ssdhip_pack_job j = jobs[blockIdx.y];
+    pack_weight_body(j.w, j.packed, j.Cout, j.Cin, j.R, j.S, j.rows_pad, j.inner_pad, j.KP, j.mode);
 }
 
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
@@ -761,6 +772,15 @@ int ssdhip_pack_conv_weight(const float* w_oihw, float* packed, int Cout, int Ci
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, Cout, Cin, R, S, rows_pad,
                        inner_pad, KP, mode);
+    SSDHIP_CHECK_LAUNCH();
+    return SSDHIP_OK;
+}
+
+int ssdhip_pack_conv_weights(const ssdhip_pack_job* jobs_device, int n_jobs, int64_t max_elements, void* stream) {
+    SSDHIP_REQUIRE(jobs_device && n_jobs > 0 && n_jobs <= 65535 && max_elements > 0, "pack_conv_weights: bad arguments");
+    int blocks = (int)((max_elements + 255) / 256);
+    if (blocks > 512) blocks = 512;                      // per job; grid-stride inside
+    hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(blocks, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_device);
     SSDHIP_CHECK_LAUNCH();
     return SSDHIP_OK;
 }

@@ -138,6 +138,7 @@ class Engine:
         # opt-in (SSD_PQ_CUS=208): CUs the persistent work-queue plane GEMM fills (ssdhip_conv_params.max_cus); 208 of 256 beside the tail: 9.53 vs 9.57 ms per
         # step -- not the default: the launch the bench line's `roofline` prices would then run on 13/16 of the chip by design
         self._pq_cus = int(os.environ.get('SSD_PQ_CUS', '0'))
+        self._pack_table = None     # (signature, device table, largest job) of the batched weight re-layout (_pack_many)
         self._fused_min = int(os.environ.get('SSD_FUSED_MIN', '70'))      # smallest map side that runs on the fused Winograd kernel
         # phased execution (graph_step.py): the frozen backbone and the trainable tail as two separately enqueued (captured) pieces.
         # What the tail reads of the backbone -- z and BN state of the stages with a detector head and of the last frozen stage --
@@ -171,6 +172,47 @@ class Engine:
                                                         spec.rows_pad_d, spec.co_pad, spec.KPd, 1, _lib.stream()), 'pack_conv_weight')
             spec.packed_d_key = key
         return spec.packed_d
+
+    def _pack_many(self, items):
+        """The (spec, dgrad) layouts of _pack whose keys are stale, in ONE launch (ssdhip_pack_conv_weights): an optimizer step changes every
+        trainable weight, i.e. ~26 five-microsecond launches per step otherwise.  The job table lives on the device and is rebuilt only when a
+        pointer in it changes."""
+        stale = []
+        for spec, dgrad in items:
+            w, _ = self._weight(spec)
+            _lib.require_gpu(w)
+            key = (w.data_ptr(), w._version, self.m._hip_epoch if not spec.frozen else 0)
+            if not dgrad:
+                if spec.packed is None or spec.packed.device != w.device:
+                    spec.packed = torch.empty(spec.rows_pad * spec.KP, device=w.device, dtype=torch.float32)
+                    spec.packed_key = None
+                if spec.packed_key != key:
+                    stale.append((spec, False, w, spec.packed, (spec.cout, spec.cin, spec.k, spec.k, spec.rows_pad, spec.cin_pad, spec.KP, 0), key))
+            else:
+                if spec.packed_d is None or spec.packed_d.device != w.device:
+                    spec.packed_d = torch.empty(spec.rows_pad_d * spec.KPd, device=w.device, dtype=torch.float32)
+                    spec.packed_d_key = None
+                if spec.packed_d_key != key:
+                    stale.append((spec, True, w, spec.packed_d, (spec.cout, spec.cin, spec.k, spec.k, spec.rows_pad_d, spec.co_pad, spec.KPd, 1), key))
+        if len(stale) < 2:
+            for spec, dgrad, *_ in stale:
+                self._pack(spec, dgrad=dgrad)
+            return
+        sig = tuple((w.data_ptr(), dst.data_ptr()) + prm for _, _, w, dst, prm, _ in stale)
+        if self._pack_table is None or self._pack_table[0] != sig:
+            import numpy as np
+            rec = np.zeros(len(stale), dtype=np.dtype([('w', '<u8'), ('packed', '<u8'), ('p', '<i4', (8,))]))      # ssdhip_pack_job: 48 bytes
+            for r, (_, _, w, dst, prm, _) in zip(rec, stale):
+                r['w'], r['packed'], r['p'] = w.data_ptr(), dst.data_ptr(), prm
+            dev = stale[0][2].device
+            self._pack_table = (sig, torch.from_numpy(rec.view(np.uint8).copy()).to(dev), max(prm[4] * prm[6] for *_, prm, _ in stale))
+        _, table, biggest = self._pack_table
+        _lib.check(self.lib.ssdhip_pack_conv_weights(_lib.ptr(table), len(stale), biggest, _lib.stream()), 'pack_conv_weights')
+        for spec, dgrad, _, _, _, key in stale:
+            if dgrad:
+                spec.packed_d_key = key
+            else:
+                spec.packed_key = key
 
     def _bn_state(self, name, c, dev, slot=0):
         key = name if slot == 0 else (name, slot)
@@ -667,6 +709,7 @@ class Engine:
             # the optimizer just changed every trainable weight: repack them (forward + data-gradient layouts, Winograd U) on the
             # side stream while the frozen backbone runs; the later _pack / _wino_weights calls find their keys current
             with fork.side():
+                plain = []               # layouts of the implicit-GEMM kernels: one batched launch (_pack_many)
                 for i, (s, g) in enumerate(zip(self.stages, geo)):       # includes det_4_3 on the frozen conv_4_3
                     for spec in (s.conv, s.head):
                         if spec is None or spec.frozen:
@@ -676,9 +719,10 @@ class Engine:
                         elif not self.bf16 and ((spec.wino and self._wino_ok(g)) or (spec.is_head and i in b['head_v'])):
                             self._wino_weights(spec)
                         else:
-                            self._pack(spec)
+                            plain.append((spec, False))
                         if i > self.tail_start or spec.is_head and i >= self.tail_start:
-                            self._pack(spec, dgrad=True)
+                            plain.append((spec, True))
+                self._pack_many(plain)
             prepacked = fork.mark()
         else:
             prepacked = None
