@@ -264,6 +264,14 @@ int ssdhip_bn_relu_bwd_finalize(const float* partial, int MB, int C, int64_t M, 
  * (feeds dgrad/wgrad of one detector head; inverse of the zero-copy concat of model/ssd.py:103-104)        */
 int ssdhip_scatter_head_grad(const float* grad, float* out, int N, int P, int row, int prior_offset, int HW,
                              int Cout, int Cpad, void* stream);
+/* all heads in one launch: `jobs_device` = n_jobs records in DEVICE memory (one per head: the arguments of ssdhip_scatter_head_grad that
+ * differ between heads, validated by the caller); max_elements = the largest N * HW * Cpad among them */
+typedef struct {
+    float* out;
+    int32_t prior_offset, HW, Cout, Cpad;
+} ssdhip_scatter_job;
+int ssdhip_scatter_head_grads(const float* grad, const ssdhip_scatter_job* jobs_device, int n_jobs, int N, int P, int row, int64_t max_elements,
+                              void* stream);
 int ssdhip_bn_relu_bwd_apply(const float* z, const float* da, const float* scale, const float* shift,
                              const float* save_mean, const float* save_invstd, const float* coef,
                              int64_t M, int C, float* dz, void* stream);

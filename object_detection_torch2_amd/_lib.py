@@ -91,6 +91,7 @@ SIGNATURES = {
     'ssdhip_bn_relu_bwd_apply': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                          c_void_p, c_void_p]),
     'ssdhip_scatter_head_grad': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'ssdhip_scatter_head_grads': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     'ssdhip_adam_multi_tensor': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'ssdhip_adam_tick': (c_int, [c_void_p, c_void_p, c_void_p]),
     'ssdhip_conv_rgb3x3_stat_rows': (c_int, [c_int, c_int, c_int]),

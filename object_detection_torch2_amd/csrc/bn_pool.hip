@@ -299,15 +299,25 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float4* __
 }
 
 // dense (N, P, row) loss gradient -> per-head channel-padded NHWC gradient (N, HW, Cpad), pad channels zero
-__global__ void scatter_head_grad_kernel(const float* __restrict__ grad, float* __restrict__ out, int P, int row, int off,
-                                         int HW, int Cout, int Cpad, int64_t total) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void scatter_head_grad_body(const float* __restrict__ grad, float* __restrict__ out, int P, int row, int off,
+                                                       int HW, int Cout, int Cpad, int64_t total, int64_t i) {
     if (i >= total) return;
     const int c = (int)(i % Cpad);
     int64_t pix = i / Cpad;
     const int hw = (int)(pix % HW);
     const int64_t n = pix / HW;
     out[i] = c < Cout ? grad[(n * P + off) * row + (int64_t)hw * Cout + c] : 0.f;
+}
+__global__ void scatter_head_grad_kernel(const float* __restrict__ grad, float* __restrict__ out, int P, int row, int off,
+                                         int HW, int Cout, int Cpad, int64_t total) {
+    scatter_head_grad_body(grad, out, P, row, off, HW, Cout, Cpad, total, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+// all heads in one launch: blockIdx.y = head
+__global__ void scatter_head_grads_kernel(const float* __restrict__ grad, const ssdhip_scatter_job* __restrict__ jobs, int N, int P, int row) {
+    const ssdhip_scatter_job j = jobs[blockIdx.y];
+    const int64_t total = (int64_t)N * j.HW * j.Cpad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        scatter_head_grad_body(grad, j.out, P, row, j.prior_offset, j.HW, j.Cout, j.Cpad, total, i);
 }
 
 int stats_split(int MB, int C) {
@@ -455,6 +465,17 @@ int ssdhip_scatter_head_grad(const float* grad, float* out, int N, int P, int ro
     int64_t total = (int64_t)N * HW * Cpad;
     hipLaunchKernelGGL(scatter_head_grad_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, grad, out, P, row,
                        prior_offset, HW, Cout, Cpad, total);
+    SSDHIP_CHECK_LAUNCH();
+    return SSDHIP_OK;
+}
+
+int ssdhip_scatter_head_grads(const float* grad, const ssdhip_scatter_job* jobs_device, int n_jobs, int N, int P, int row, int64_t max_elements,
+                              void* stream) {
+    SSDHIP_REQUIRE(grad && jobs_device && n_jobs > 0 && n_jobs <= 65535 && N > 0 && P > 0 && row > 0 && max_elements > 0,
+                   "scatter_head_grads: bad arguments");
+    int blocks = (int)((max_elements + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(scatter_head_grads_kernel, dim3(blocks, n_jobs), dim3(256), 0, (hipStream_t)stream, grad, jobs_device, N, P, row);
     SSDHIP_CHECK_LAUNCH();
     return SSDHIP_OK;
 }

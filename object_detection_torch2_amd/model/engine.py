@@ -1203,8 +1203,20 @@ class Engine:
         st = _lib.stream()
         L = self.lib
         # dense (N,P,row) gradient -> channel-padded per-head NHWC gradients
-        for i, (s, g) in enumerate(zip(self.stages, geo)):
-            if s.head is not None:
+        heads = [(i, s, g) for i, (s, g) in enumerate(zip(self.stages, geo)) if s.head is not None]
+        sig = tuple(bw['dyh'][i].data_ptr() for i, _, _ in heads)
+        if len(heads) > 1:            # one launch for all heads (device job table, rebuilt only when a gradient buffer moves)
+            tbl = bw.get('scatter_table')
+            if tbl is None or tbl[0] != sig:
+                import numpy as np
+                rec = np.zeros(len(heads), dtype=np.dtype([('out', '<u8'), ('p', '<i4', (4,))]))          # ssdhip_scatter_job: 24 bytes
+                for r, (i, s, g) in zip(rec, heads):
+                    r['out'], r['p'] = bw['dyh'][i].data_ptr(), (b['head_off'][s.head_index], g['ho'] * g['wo'], s.head.cout, s.head.co_pad)
+                tbl = bw['scatter_table'] = (sig, torch.from_numpy(rec.view(np.uint8).copy()).to(grad_out.device),
+                                            max(N * g['ho'] * g['wo'] * s.head.co_pad for _, s, g in heads))
+            _lib.check(L.ssdhip_scatter_head_grads(_lib.ptr(grad_out), _lib.ptr(tbl[1]), len(heads), N, b['P'], self.row, tbl[2], st), 'scatter_head_grads')
+        else:
+            for i, s, g in heads:
                 _lib.check(L.ssdhip_scatter_head_grad(_lib.ptr(grad_out), _lib.ptr(bw['dyh'][i]), N, b['P'], self.row,
                                                       b['head_off'][s.head_index], g['ho'] * g['wo'], s.head.cout, s.head.co_pad, st),
                            'scatter_head_grad')
