@@ -128,6 +128,7 @@ class Engine:
         if self._wino_mode not in ('f2', 'f4'):
             raise ValueError(f"SSD_WINOGRAD must be 'f2' or 'f4', got {self._wino_mode!r}")
         self._pool_fuse = os.environ.get('SSD_NO_POOL_FUSE') != '1'      # A/B: conv + 2x2 max-pool without materialising z (conv_1_2, conv_2_2)
+        self._pool_xform = os.environ.get('SSD_POOL_XFORM') == '1'       # A/B: the layer behind a fused pool reads the stored extreme and applies BatchNorm.ReLU on load
         self._pool_pair = os.environ.get('SSD_POOL_PAIR') == '1'         # A/B: the pooled epilogue stores window maxima AND minima (round-3 form) instead of the one the pool uses
         self._w4_max_map = int(os.environ.get('SSD_W4_MAX_MAP', '160'))     # largest map side on the F(4x4) passes (SSD512: conv_3_2 / conv_3_3 at 128 px)
         self._early_f4 = os.environ.get('SSD_EARLY_F4', '0') == '1'       # opt-in: conv_2_2 / conv_3_1 on the two-pass F(4x4) form (csrc/wino4_fused.hip)
@@ -939,13 +940,18 @@ class Engine:
                 elif pool_fused:
                     pooled = b['pooled'][i] if not alt else self._alt(b, 'pooled', i, b['pooled'][i])
                     zmm = b['zmm'][i]
-                    if zmm.shape[0] == 1:       # the producer stored the extreme the pool uses: BatchNorm.ReLU of it IS the pooled activation
+                    if zmm.shape[0] == 1 and self._pool_xform and self._fused_ok(self.stages[i + 1].conv, geo[i + 1], N) and not self._early_f4:
+                        # A/B (SSD_POOL_XFORM=1): no pooled activation in memory at all -- the next layer's fused kernel applies this
+                        # BatchNorm.ReLU on load, like the layers without a pool in between (bit-identical: the same fma and max)
+                        cur, cur_xs = zmm[0], act_xs
+                    elif zmm.shape[0] == 1:     # the producer stored the extreme the pool uses: BatchNorm.ReLU of it IS the pooled activation
                         _lib.check(self.lib.ssdhip_bn_relu_pool(_lib.ptr(zmm[0]), _lib.ptr(bst['scale']), _lib.ptr(bst['shift']), _lib.ptr(pooled),
                                                                 N, g['ha'], g['wa'], c.cout, 0, 0, st), f'pool (selected extreme) after {c.name}')
+                        cur, cur_xs = pooled, None
                     else:
                         _lib.check(self.lib.ssdhip_bn_relu_select(_lib.ptr(zmm[0]), _lib.ptr(zmm[1]), _lib.ptr(bst['scale']), _lib.ptr(bst['shift']),
                                                                   _lib.ptr(pooled), N * g['ha'] * g['wa'], c.cout, st), f'pool (select) after {c.name}')
-                    cur, cur_xs = pooled, None
+                        cur, cur_xs = pooled, None
                 elif s.pool_pad is not None:
                     pooled = b['pooled'][i] if not alt else self._alt(b, 'pooled', i, b['pooled'][i])
                     _lib.check(self.lib.ssdhip_bn_relu_pool(_lib.ptr(z), _lib.ptr(bst['scale']), _lib.ptr(bst['shift']), _lib.ptr(pooled),
