@@ -496,10 +496,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 //   stage   thread (hh = wave & 1, q = (wave >> 1) & 1, tile = 32 (wave >> 2) + lane / 2, channel pair = lane & 1): half a patch x 2
 //           channels (8-B LDS accesses)
 //   DMA     weight image: 4 pieces per wave; raw tile: waves 0-3 three pieces, waves 4-7 two; record: waves 0-3
+//   PRE     (round 4, the form launched for layers with a fused BatchNorm.ReLU input) the activation is applied ONCE per raw-tile element, in place, by
+//           the wave that fetched the piece (its pieces lie in one channel quad: one scale / shift), between the tile's arrival and the patch reads
 #ifndef WF8_MIDP
 #define WF8_MIDP 1      // plane slot of the mid-step barrier + raw-tile refill (A/B: -DWF8_MIDP=2 / 3)
 #endif
-template <bool XFORM, int ABL = 0, int POOL = 0>       // ABL: timing-only ablations (probe builds; wrong results): 1 no raw-tile DMA, 2 no weight DMA, 4 no transform, 8 no stores; POOL: 1 = store window max / min instead of z, 2 = only the one of them the pool will use
+template <bool XFORM, int ABL = 0, int POOL = 0, bool PRE = false>       // PRE (with XFORM): the activation runs ONCE per raw-tile element, in place, before the patches are read (see the loop); ABL: timing-only ablations (probe builds; wrong results): 1 no raw-tile DMA, 2 no weight DMA, 4 no transform, 8 no stores; POOL: 1 = store window max / min instead of z, 2 = only the one of them the pool will use
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_fused8_kernel(WfArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -532,8 +534,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // staging role: wave = (patch half hh, channel quad q, 32 tiles tg); lane = (tile, channel pair): the two lanes of a tile read /
     // write the two 8-B halves of the same 16-B unit, so a 32-lane access group covers 16 consecutive units = all 64 banks once
     const int hh = wave & 1, q = (wave >> 1) & 1, tile_l = 32 * (wave >> 2) + (lane >> 1), half = lane & 1;
-    // raw-tile DMA pieces of this wave: piece ids P = 0 .. 19 (quad P / 10, 64 slots P % 10)
-    const int np = wave < 4 ? 3 : 2, p_first = wave < 4 ? 3 * wave : 12 + 2 * (wave - 4);
+    // raw-tile DMA pieces of this wave: piece ids P = 0 .. 19 (quad P / 10, 64 slots P % 10).  PRE: a wave's pieces lie in ONE channel quad
+    // (waves 0-3: quad 0, 4-7: quad 1; 3 + 3 + 2 + 2 pieces each), so that the wave that fetched a piece also activates it with one scale / shift
+    const int np = PRE ? ((wave & 3) < 2 ? 3 : 2) : (wave < 4 ? 3 : 2);
+    const int p_first = PRE ? 10 * (wave >> 2) + ((wave & 3) < 2 ? 3 * (wave & 3) : 6 + 2 * ((wave & 3) - 2)) : (wave < 4 ? 3 * wave : 12 + 2 * (wave - 4));
     unsigned dof[3], pb[3];
     float hi[3][4];
     int recN[3];
@@ -562,6 +566,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int k = 0; k < 3; ++k) dof[k] = recN[k] < 0 ? 0x80000000u : (unsigned)(recN[k] * a.C * 4);
     };
+    float uh[3];            // PRE: upper clamp of this lane's slot in each of the wave's pieces: +inf inside the image, 0 outside (zero padding AFTER the activation)
     auto adopt_tile = [&]() {
         const bool tv = (tileN.z >> 8) & 1;
 #pragma unroll
@@ -570,6 +575,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             pb[r] = lds0 + (unsigned)(WF_RAW_OFF + q * WF_QUAD + half * 8 + (tv ? ((tileN.x + pr * tileN.y) >> 1) * 16 : 0));
 #pragma unroll
             for (int j = 0; j < 4; ++j) hi[r][j] = (((tileN.z >> pr) & 1) && ((tileN.z >> (4 + j)) & 1)) ? __builtin_inff() : 0.0f;
+        }
+        // the raw tile the NEXT step's pre-pass finds was fetched with the slots adopted one step ago (adopt_dof): same record entries
+        if (PRE) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) uh[k] = recN[k] < 0 ? 0.0f : __builtin_inff();
         }
     };
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
@@ -599,16 +609,41 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(P[r][j]) : "v"(pb[r]), "n"((j & 1) * (WF_SLOTS / 2) * 16 + (j >> 1) * 16));
-        if (XFORM) {
+        if (XFORM && !PRE) {
             asm volatile("ds_read_b64 %0, %1" : "=v"(sc) : "v"(ss_rd + (unsigned)(g * 32)));
             asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(sh) : "v"(ss_rd + (unsigned)(g * 32)), "n"(WF_MAXC * 4));
+        }
+    };
+    // PRE: the wave's raw-tile pieces, activated in place (each 16-B unit = one slot x the quad's 4 channels; lane = slot): 3 reads (the third
+    // a repeat of the first on the waves that own two pieces: never written back) + scale / shift of the quad, 12 (8) fma + med3, 3 (2) writes
+    f32x4 U[3], scq, shq;
+    const unsigned u_rd = lds0 + (unsigned)(WF_RAW_OFF + (p_first / 10) * WF_QUAD + (p_first % 10) * 1024 + lane * 16);
+    const unsigned sq_rd = lds0 + (unsigned)(WF_SS_OFF + (p_first / 10) * 16);
+    auto pre_read = [&](int g) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(U[0]) : "v"(u_rd));
+        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(U[1]) : "v"(u_rd));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(U[2]) : "v"(u_rd + (unsigned)(np == 3 ? 2048 : 0)));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(scq) : "v"(sq_rd + (unsigned)(g * 32)));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(shq) : "v"(sq_rd + (unsigned)(g * 32)), "n"(WF_MAXC * 4));
+    };
+#define WF8_TIE_U() asm volatile("" : "+v"(U[0]), "+v"(U[1]), "+v"(U[2]), "+v"(scq), "+v"(shq))
+    auto pre_act_write = [&]() {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (k == 2 && np < 3) break;
+            f32x4 v = U[k];
+            v.x = __builtin_amdgcn_fmed3f(__builtin_fmaf(v.x, scq.x, shq.x), 0.f, uh[k]);
+            v.y = __builtin_amdgcn_fmed3f(__builtin_fmaf(v.y, scq.y, shq.y), 0.f, uh[k]);
+            v.z = __builtin_amdgcn_fmed3f(__builtin_fmaf(v.z, scq.z, shq.z), 0.f, uh[k]);
+            v.w = __builtin_amdgcn_fmed3f(__builtin_fmaf(v.w, scq.w, shq.w), 0.f, uh[k]);
+            asm volatile("ds_write_b128 %0, %1" ::"v"(u_rd + (unsigned)(k * 1024)), "v"(v) : "memory");
         }
     };
 #define WF8_TIE_P()                                                                                                                  \
     asm volatile("" : "+v"(P[0][0]), "+v"(P[0][1]), "+v"(P[0][2]), "+v"(P[0][3]), "+v"(P[1][0]), "+v"(P[1][1]), "+v"(P[1][2]),        \
                       "+v"(P[1][3]), "+v"(P[2][0]), "+v"(P[2][1]), "+v"(P[2][2]), "+v"(P[2][3]), "+v"(sc), "+v"(sh))
     auto act = [&](f32x2 f, float h) -> f32x2 {
-        if (XFORM) {
+        if (XFORM && !PRE) {
             f.x = __builtin_amdgcn_fmed3f(__builtin_fmaf(f.x, sc.x, sh.x), 0.f, h);
             f.y = __builtin_amdgcn_fmed3f(__builtin_fmaf(f.y, sc.y, sh.y), 0.f, h);
         }
@@ -651,6 +686,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     dma_b(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (PRE) {
+        pre_read(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        WF8_TIE_U();
+        pre_act_write();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
     read_patch(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     WF8_TIE_P();
@@ -702,7 +745,38 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fa[c ^ 1]) : "v"(ab), "n"((p + 1) * WF_PLANE));
                     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[c ^ 1]) : "v"(bb), "n"((p + 1) * WF_PLANE));
                 }
-                if (p == 0) {
+                if (PRE) {
+                    // Side work with the pre-pass: p = 0 the wave's raw-tile units of step s + 1 are requested (they landed before the last barrier),
+                    // p = 1 activated in place (behind the MFMAs), p = 2 barrier, then every thread reads its patch from the ACTIVATED tile,
+                    // p = 3 barrier + refill of the raw tile for step s + 2, p = 4..7 row pass (no activation left in it), p = 8, 9 A image.
+                    if (p == 0) {
+                        dma_b(g1);
+                        if (g == 0) dma_rec(jn, j + 1);
+                        pre_read(g1);
+                        if (g == KT - 3) read_slots(j + 1);
+                        if (g == KT - 2) read_tile(j + 1);
+                        // newer than this plane's fragments: the next plane's two and the five pre-pass reads (more at the two special steps: stricter)
+                        asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(fa[c]), "+v"(fb[c]));
+                    } else if (p == 1) {
+                        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[c]), "+v"(fb[c]));
+                        WF8_TIE_U();
+                        WF8_TIE_SLOTS();
+                        WF8_TIE_TILE();
+                    } else if (p == 2) {
+                        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[c]), "+v"(fb[c]));       // ... also retires this thread's in-place stores
+                        __builtin_amdgcn_s_barrier();
+                        read_patch(g1);
+                    } else if (p == 3) {
+                        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[c]), "+v"(fb[c]));       // ... and the patch reads
+                        WF8_TIE_P();
+                        __builtin_amdgcn_s_barrier();
+                        dma_raw(g2);
+                    } else if (p < 15) {
+                        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[c]), "+v"(fb[c]));
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[c]), "+v"(fb[c]));
+                    }
+                } else if (p == 0) {
                     if (!(ABL & 2)) dma_b(g1);
                     if (g == 0) dma_rec(jn, j + 1);
                     read_patch(g1);
@@ -727,9 +801,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].x, fb[c].z, acc[p][1], 0, 0, 0);
                 acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].y, fb[c].y, acc[p][0], 0, 0, 0);
                 acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].y, fb[c].w, acc[p][1], 0, 0, 0);
-                if (p >= 2 && p < 6 && !(ABL & 4) && !(ABL & 32)) rows_of(p - 2);        // 32: no row pass (activation + B^T d)
-                if (p == 6 && !(ABL & 4) && !(ABL & 16)) planes_of(0, nxt);                // 16: no column pass / A-image stores
-                if (p == 7 && !(ABL & 4) && !(ABL & 16)) planes_of(1, nxt);
+                if (PRE) {
+                    if (p == 1) pre_act_write();
+                    if (p >= 4 && p < 8) rows_of(p - 4);
+                    if (p == 8) planes_of(0, nxt);
+                    if (p == 9) planes_of(1, nxt);
+                } else {
+                    if (p >= 2 && p < 6 && !(ABL & 4) && !(ABL & 32)) rows_of(p - 2);        // 32: no row pass (activation + B^T d)
+                    if (p == 6 && !(ABL & 4) && !(ABL & 16)) planes_of(0, nxt);                // 16: no column pass / A-image stores
+                    if (p == 7 && !(ABL & 4) && !(ABL & 16)) planes_of(1, nxt);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -832,6 +913,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef WF8_TIE_P
 #undef WF8_TIE_SLOTS
 #undef WF8_TIE_TILE
+#undef WF8_TIE_U
 }
 
 }  // namespace
@@ -964,6 +1046,25 @@ static int wino_fused_launch(const float* x, const float* upk, const float* bias
         return a.MB;
     }
 #endif
+    // the producer's BatchNorm.ReLU as an in-place pre-pass over the raw tile (default; SSD_WF_PRE=0: inside the row pass, the round-2 form):
+    // 69 instead of 94 VALU instructions per thread and K-step -- the 4 x 4 patches of neighbouring tiles overlap and the two half-patch threads
+    // of a tile share two rows, so the row pass activated every element ~5 times -- for one more barrier per K-step: conv_2_2 0.970 -> 0.945 ms,
+    // conv_1_2 1.173 -> 1.155, the step 9.585 -> 9.523 ms (two alternating runs on one box), bit-identical results
+    static const bool pre = [] { const char* e = getenv("SSD_WF_PRE"); return !(e && atoi(e) == 0); }();
+    if (pre && in_scale) {
+        static DeviceOnce once;
+        if (const int d = once.pending(); d != DeviceOnce::kDone) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused8_kernel<true, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused8_kernel<true, 0, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused8_kernel<true, 0, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS);
+            once.mark(d);
+        }
+        if (zmax != nullptr && gsel != nullptr) hipLaunchKernelGGL((wino_fused8_kernel<true, 0, 2, true>), grid, dim3(512), WF_LDS, st, a);
+        else if (zmax != nullptr) hipLaunchKernelGGL((wino_fused8_kernel<true, 0, 1, true>), grid, dim3(512), WF_LDS, st, a);
+        else hipLaunchKernelGGL((wino_fused8_kernel<true, 0, 0, true>), grid, dim3(512), WF_LDS, st, a);
+        SSDHIP_CHECK_LAUNCH();
+        return a.MB;
+    }
     if (zmax != nullptr && gsel != nullptr) {
         if (in_scale) hipLaunchKernelGGL((wino_fused8_kernel<true, 0, 2>), grid, dim3(512), WF_LDS, st, a);
         else hipLaunchKernelGGL((wino_fused8_kernel<false, 0, 2>), grid, dim3(512), WF_LDS, st, a);

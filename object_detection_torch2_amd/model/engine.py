@@ -870,7 +870,8 @@ class Engine:
                         e1.record()
                         tiles = N * ((g['hi'] + 1) // 2) * ((g['wi'] + 1) // 2)
                         self.prof.append(dict(layer=c.name + ' (fused Winograd)', e0=e0, e1=e1,
-                                              kernel='wino_fused8_kernel<%s, 0, %d>' % ('true' if cur_xs is not None else 'false', (2 if zmm.shape[0] == 1 else 1) if pool_fused else 0),
+                                              kernel='wino_fused8_kernel<%s, 0, %d, %s>' % ('true' if cur_xs is not None else 'false', (2 if zmm.shape[0] == 1 else 1) if pool_fused else 0,
+                                                                                        'true' if (cur_xs is not None and os.environ.get('SSD_WF_PRE') != '0') else 'false'),
                                               flops=2.0 * 16 * tiles * c.cin * c.cout,            # MFMA flops of the 16 Winograd-domain products
                                               direct_flops=2.0 * N * g['hi'] * g['wi'] * c.cin * c.cout * 9))
                 elif c.wino and self._wino_ok(g) and not self.bf16:     # bf16 MFMA outruns the fp32 Winograd pipeline: direct kernel
