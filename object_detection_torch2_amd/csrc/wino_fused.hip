@@ -1050,7 +1050,8 @@ static int wino_fused_launch(const float* x, const float* upk, const float* bias
     // 69 instead of 94 VALU instructions per thread and K-step -- the 4 x 4 patches of neighbouring tiles overlap and the two half-patch threads
     // of a tile share two rows, so the row pass activated every element ~5 times -- for one more barrier per K-step: conv_2_2 0.970 -> 0.945 ms,
     // conv_1_2 1.173 -> 1.155, the step 9.585 -> 9.523 ms (two alternating runs on one box), bit-identical results
-    static const bool pre = [] { const char* e = getenv("SSD_WF_PRE"); return !(e && atoi(e) == 0); }();
+    const char* pre_env = getenv("SSD_WF_PRE");          // read per launch (not latched): the route test toggles it inside one process
+    const bool pre = !(pre_env && atoi(pre_env) == 0);
     if (pre && in_scale) {
         static DeviceOnce once;
         if (const int d = once.pending(); d != DeviceOnce::kDone) {

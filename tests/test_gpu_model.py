@@ -568,12 +568,15 @@ def test_pool_fusion_is_bit_identical(env, monkeypatch):
 
 
 @pytest.mark.parametrize('switches', [dict(SSD_NO_FUSED_WINOGRAD='1'), dict(SSD_NO_FUSED_WINOGRAD='1', SSD_WINOGRAD='f2'), dict(SSD_NO_PLANE_QUEUE='1'),
-                                      dict(SSD_NO_SPLITK='1', SSD_NO_POOL_FUSE='1'), dict(SSD_PLANE_GEMM='bf16x3'), dict(SSD_EARLY_F4='1')])
+                                      dict(SSD_NO_SPLITK='1', SSD_NO_POOL_FUSE='1'), dict(SSD_PLANE_GEMM='bf16x3'), dict(SSD_EARLY_F4='1'),
+                                      dict(SSD_WF_PRE='0'), dict(SSD_POOL_PAIR='1'), dict(SSD_POOL_XFORM='1'), dict(SSD_PQ_CUS='208')])
 def test_fallback_routes_run_the_same_network(env, golden, monkeypatch, switches):
     """The kernels the default route no longer launches stay part of the product (A/B switches, other shapes): conv_c64 for conv_1_2 /
     conv_2_1 and the three-pass Winograd forms for the wide maps (SSD_NO_FUSED_WINOGRAD), the one-slot-per-block plane GEMM
     (SSD_NO_PLANE_QUEUE), the un-split tiny-map launches and the unfused pool (SSD_NO_SPLITK, SSD_NO_POOL_FUSE), and the opt-in two-pass F(4x4)
-    form of conv_2_2 / conv_3_1 (SSD_EARLY_F4: plain and pooled epilogue, BatchNorm partial sums).  Each route must be the
+    form of conv_2_2 / conv_3_1 (SSD_EARLY_F4: plain and pooled epilogue, BatchNorm partial sums), the round-2 / round-3 forms of the fused
+    kernel's activation and pooled epilogue (SSD_WF_PRE=0, SSD_POOL_PAIR, SSD_POOL_XFORM: bit-identical to the default) and the capped grid of the
+    work-queue plane GEMM (SSD_PQ_CUS).  Each route must be the
     same network at model level: forward against the reference's golden rows at the bound of the default route, and against the default
     route's own output at rounding level."""
     synth = env['synth']
@@ -593,3 +596,5 @@ def test_fallback_routes_run_the_same_network(env, golden, monkeypatch, switches
     assert d[:, :8692].max().item() < 1e-3 and d.max().item() < 4e-3      # the 3x3 / 1x1 maps of a batch of two amplify (BatchNorm over 18 / 2 samples)
     if 'SSD_NO_FUSED_WINOGRAD' in switches or 'SSD_EARLY_F4' in switches:
         assert not torch.equal(y0, y1)                                   # a different set of kernels really ran
+    if any(k in switches for k in ('SSD_WF_PRE', 'SSD_POOL_PAIR', 'SSD_POOL_XFORM')):
+        assert torch.equal(y0, y1)                                       # the same arithmetic on the same elements, staged differently                                   # a different set of kernels really ran
