@@ -43,7 +43,9 @@ struct WgradArgs {
     int plane_mode;
 };
 
-template <bool XFORM>
+// PLANE: the Winograd-domain use (a.plane_mode): rows are plain -- no (n, ho, wo) decode, no spatial bounds; the generic index arithmetic was
+// ~160 of the 222 VALU instructions of a K-step, on the lanes the fp32 MFMAs run on
+template <bool XFORM, bool PLANE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_kernel(WgradArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TK * TM];
     float* As = lds;                 // [2][TK][TM]  dy rows
@@ -83,14 +85,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     {                                                                                                                 \
         const int m = st_ * TK + lrow + 8 * I;                                                                        \
         const bool mok = m < a.M;                                                                                     \
-        const int n = fastdiv(m, a.dHoWo);                                                                            \
-        const int rem = m - n * a.HoWo;                                                                               \
-        const int ho = fastdiv(rem, a.dWo), wo = rem - ho * a.Wo;                                                     \
-        const int hi = ho * a.stride - a.pad + r, wi = wo * a.stride - a.pad + s;                                     \
-        const bool aok = mok && co_ok;                                                                                \
-        const bool bok = mok && ci_ok && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi;              \
-        const size_t aoff = aok ? (size_t)n * a.dy_batch_stride + (size_t)rem * a.CoutRow + co : (size_t)0;           \
-        const size_t boff = bok ? ((size_t)(n * a.Hi + hi) * a.Wi + wi) * a.Cin + ci : (size_t)0;                     \
+        bool aok, bok;                                                                                                \
+        size_t aoff, boff;                                                                                            \
+        if (PLANE) {                                                                                                  \
+            aok = mok && co_ok; bok = mok && ci_ok;                                                                   \
+            aoff = aok ? (size_t)m * a.CoutRow + co : (size_t)0;                                                      \
+            boff = bok ? (size_t)m * a.Cin + ci : (size_t)0;                                                          \
+        } else {                                                                                                      \
+            const int n = fastdiv(m, a.dHoWo);                                                                        \
+            const int rem = m - n * a.HoWo;                                                                           \
+            const int ho = fastdiv(rem, a.dWo), wo = rem - ho * a.Wo;                                                 \
+            const int hi = ho * a.stride - a.pad + r, wi = wo * a.stride - a.pad + s;                                 \
+            aok = mok && co_ok;                                                                                       \
+            bok = mok && ci_ok && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi;                     \
+            aoff = aok ? (size_t)n * a.dy_batch_stride + (size_t)rem * a.CoutRow + co : (size_t)0;                    \
+            boff = bok ? ((size_t)(n * a.Hi + hi) * a.Wi + wi) * a.Cin + ci : (size_t)0;                              \
+        }                                                                                                             \
         ra##I = *reinterpret_cast<const float4*>(dybase + aoff);                                                      \
         rb##I = *reinterpret_cast<const float4*>(xbase + boff);                                                       \
         amask |= (aok ? 1u : 0u) << I;                                                                                \
@@ -712,7 +722,7 @@ int ssdhip_conv2d_wgrad_winograd(const ssdhip_wgrad_params* p, void* stream) {
                        reinterpret_cast<float4*>(dM), p->Hi, p->Wi, C4, TH, TW, T, Tp);
     SSDHIP_CHECK_LAUNCH();
     // 3. 16 plane products on the wgrad MFMA kernel (split-K slabs)
-    hipLaunchKernelGGL(wgrad_kernel<false>, dim3(a.CB * a.IB * a.taps * a.splitK), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((wgrad_kernel<false, true>), dim3(a.CB * a.IB * a.taps * a.splitK), dim3(256), 0, st, a);
     SSDHIP_CHECK_LAUNCH();
     // 4. dW = G^T (sum of slabs) G, OIHW
     int64_t total = (int64_t)p->Cout * p->Cin;
@@ -775,7 +785,7 @@ int ssdhip_conv2d_wgrad_winograd4(const ssdhip_wgrad_params* p, void* stream) {
     hipLaunchKernelGGL(winograd4_outgrad_kernel, dim3(cdiv((int64_t)T * C4, 256)), dim3(256), 0, st, reinterpret_cast<const float4*>(p->dy),
                        reinterpret_cast<float4*>(dM), p->Hi, p->Wi, C4, TH, TW, T, Tp);
     SSDHIP_CHECK_LAUNCH();
-    hipLaunchKernelGGL(wgrad_kernel<false>, dim3(a.CB * a.IB * a.taps * a.splitK), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((wgrad_kernel<false, true>), dim3(a.CB * a.IB * a.taps * a.splitK), dim3(256), 0, st, a);
     SSDHIP_CHECK_LAUNCH();
     int splits_left = a.splitK;
     if (a.splitK > 1) {
