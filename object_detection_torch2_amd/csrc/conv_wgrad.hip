@@ -657,8 +657,17 @@ int ssdhip_conv2d_wgrad(const ssdhip_wgrad_params* p, void* stream) {
     if (p->compute == 1) {
         if (p->in_scale) hipLaunchKernelGGL(wgrad_bf16_kernel<true>, grid, block, 0, st, a);
         else hipLaunchKernelGGL(wgrad_bf16_kernel<false>, grid, block, 0, st, a);
-    } else if (p->in_scale) hipLaunchKernelGGL(wgrad_kernel<true>, grid, block, 0, st, a);
-    else hipLaunchKernelGGL(wgrad_kernel<false>, grid, block, 0, st, a);
+    } else {
+        // 1x1 / stride 1 / pad 0 on dense gradients (conv_7 and the 1x1 extras): output pixel m reads input pixel m -- the plain-row form
+        const bool flat = a.KS == 1 && a.stride == 1 && a.pad == 0 && a.Hi == a.Ho && a.Wi == a.Wo && a.dy_batch_stride == (long long)a.HoWo * a.CoutRow;
+        if (p->in_scale) {
+            if (flat) hipLaunchKernelGGL((wgrad_kernel<true, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL(wgrad_kernel<true>, grid, block, 0, st, a);
+        } else {
+            if (flat) hipLaunchKernelGGL((wgrad_kernel<false, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL(wgrad_kernel<false>, grid, block, 0, st, a);
+        }
+    }
     SSDHIP_CHECK_LAUNCH();
     const int dw_cin = p->dw_cin > 0 ? p->dw_cin : p->Cin;
     SSDHIP_REQUIRE(dw_cin <= p->Cin, "wgrad: dw_cin must not exceed Cin");
